@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Headline benchmark: megapixels/s denoised, UtNet(64,'PReLU') fp32, 24 MP synthetic frames, cs=264/ucs=200/ol=64.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+A "step" is one 6000x4000 frame through the device-resident crop -> UtNet -> stitch loop (BASELINE.json configs[1],
+geometry "G24" of SURVEY.md section 8: cs=264 is the valid tile size nearest to the named 256, which the reference
+network itself rejects).  The frame is resident in HBM when the timed region starts.  With N > 1 the tile index range
+of every frame is split into N contiguous shards (one rank per GPU); inside the timed region rank 0 broadcasts the
+frame over RCCL/xGMI, every rank denoises its shard into its own canvas and the canvases are summed onto rank 0
+(each pixel receives contributions from at most two ranks, at shard seams) -> total work per step is fixed: "strong".
+
+One JSON line on rank 0.  `roofline` prices the conv_qp_f32 kernel family (all 22 MFMA conv launches of the stack)
+against the fp32 MFMA peak with HIP events recorded on the launch stream; `cpu_baseline` times the oracle (torch CPU
+fp32, the same primitives the reference runs) on a bounded sample of the same frame's tiles.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=32, help="tiles per launch of the conv stack")
+    ap.add_argument("--width", type=int, default=6000)
+    ap.add_argument("--height", type=int, default=4000)
+    ap.add_argument("--cs", type=int, default=264)
+    ap.add_argument("--ucs", type=int, default=200)
+    ap.add_argument("--ol", type=int, default=64)
+    ap.add_argument("--funit", type=int, default=64)
+    ap.add_argument("--cpu-sample-tiles", type=int, default=0, help="0: sized for ~15 s of CPU work")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def conv_stack_profile(net, cs, batch, dev, reps=3):
+    """HIP-event timing of every launch of the conv stack for one batch (median over reps)."""
+    import numpy as np
+    import torch
+    from nind_denoise_amd import _lib
+    lib = _lib.load()
+    blob = net.packed_weights(dev)
+    ws = net.workspace(cs, batch, dev)
+    n = 26
+    ms = (ctypes.c_float * n)()
+    fl = (ctypes.c_double * n)()
+    isc = (ctypes.c_int * n)()
+    runs = []
+    for _ in range(reps + 1):
+        _lib.check(lib.nd_utnet_profile_stack(net.funit, _lib.ACT[net.activation], _lib.ND_F32, blob.data_ptr(), batch, cs,
+                                              ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev), ms, fl, isc, n))
+        runs.append(list(ms))
+    med = np.median(np.array(runs[1:]), axis=0)
+    steps = [dict(name=lib.nd_utnet_step_name(i).decode(), ms=float(med[i]), flop=float(fl[i]), conv=bool(isc[i]))
+             for i in range(n)]
+    return steps
+
+
+def cpu_baseline(frame, sd, cs, ucs, ol, n_tiles, threads):
+    """The oracle's crop -> UtNet -> stitch on `n_tiles` tiles of the frame (torch CPU fp32, grad mode off)."""
+    import numpy as np
+    import torch
+    from oracle import networks as onet
+    from oracle import tiler as otiler
+    torch.set_num_threads(threads)
+    grid = otiler.TileGrid(frame.shape[2], frame.shape[1], cs, ucs, ol)
+    canvas = np.zeros_like(frame)
+    ids = [int(i) for i in np.linspace(0, grid.size - 1, n_tiles)]
+    with torch.no_grad():
+        onet.utnet_forward(sd, torch.from_numpy(otiler.gather_tile(frame, grid, 0))[None])  # warm-up
+        t0 = time.perf_counter()
+        for i in ids:
+            x = torch.from_numpy(otiler.gather_tile(frame, grid, i))[None]
+            y = onet.utnet_forward(sd, x).numpy()
+            otiler.stitch_add(canvas, y[0], grid, i)
+        dt = time.perf_counter() - t0
+    return dt, grid.size
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from nind_denoise_amd import _lib, pipeline, synth
+    from nind_denoise_amd.networks.UtNet import UtNet
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    _lib.load()
+
+    W, H, cs, ucs, ol = args.width, args.height, args.cs, args.ucs, args.ol
+    sd = synth.make_utnet_state_dict(funit=args.funit, seed=123)
+    net = UtNet(funit=args.funit)
+    net.load_state_dict(sd)
+    net = net.eval().to(dev)
+    blob = net.packed_weights(dev)
+    if world > 1:
+        dist.broadcast(blob, src=0)  # one-time weight broadcast (rank 0 is the model owner)
+
+    frame_np = synth.make_frame(W, H, seed=24) if rank == 0 else None
+    frame = torch.from_numpy(frame_np).to(dev) if rank == 0 else torch.empty((3, H, W), dtype=torch.float32, device=dev)
+    total = pipeline.tile_count(W, H, cs, ucs, ol)
+    lo, hi = (total * rank) // world, (total * (rank + 1)) // world
+    canvas = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
+
+    def step():
+        if world > 1:
+            dist.broadcast(frame, src=0)
+        canvas.zero_()
+        pipeline.denoise_frame(net, frame, cs, ucs, ol, batch=args.batch, tile_range=(lo, hi), canvas=canvas)
+        if world > 1:
+            dist.reduce(canvas, dst=0, op=dist.ReduceOp.SUM)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    mp = W * H / 1e6
+    value = mp * args.steps / dt
+    out = {
+        "metric": "megapixels/sec denoised, UtNet cs=256 on 24 MP frames, 1/2/4/8 MI355X",
+        "value": round(value, 4),
+        "unit": "MP/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 3),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"configs[1]: one {W}x{H} ({mp:.1f} MP) fp32 frame per step, UtNet(funit={args.funit},PReLU) random-init "
+                        f"(seed 123), cs={cs} (nearest valid to 256; the reference rejects 256) ucs={ucs} ol={ol} -> {total} tiles, "
+                        f"tiles per conv-stack launch {args.batch}, crop->infer->stitch device resident",
+            "tiles_per_frame": total,
+            "flop_per_frame": net.flops_per_tile(cs) * total,
+            "parallelism": f"tile-shard x{world}" if world > 1 else "single GPU",
+        },
+    }
+
+    if rank == 0:
+        flop_frame = net.flops_per_tile(cs) * total
+        out["end_to_end_tflops"] = round(flop_frame * args.steps / dt / 1e12, 3)
+        if not args.no_roofline and world == 1:
+            b = min(args.batch, total)
+            steps = conv_stack_profile(net, cs, b, dev)
+            conv_ms = sum(s["ms"] for s in steps if s["conv"])
+            conv_flop = sum(s["flop"] for s in steps if s["conv"])
+            achieved = conv_flop / (conv_ms * 1e-3) / 1e12
+            out["roofline"] = {
+                "bound": "mfma",
+                "kernel": "conv_qp_f32 (22 launches per tile batch: every 3x3 / transposed conv of UtNet)",
+                "achieved": round(achieved, 3),
+                "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                "traffic": None,
+                "launches": len([s for s in steps if s["conv"]]),
+                "avg_launch_ms": round(conv_ms / max(1, len([s for s in steps if s["conv"]])), 4),
+                "algorithmic_flop_per_launch_avg": conv_flop / max(1, len([s for s in steps if s["conv"]])),
+                "tiles_per_launch": b,
+                "stack_ms_per_batch": round(sum(s["ms"] for s in steps), 4),
+                "per_layer": [dict(name=s["name"], ms=round(s["ms"], 4),
+                                   tflops=round(s["flop"] / max(s["ms"], 1e-9) / 1e9, 2)) for s in steps],
+            }
+        if not args.no_cpu_baseline and world == 1:
+            threads = os.cpu_count() or 1
+            try:
+                threads = len(os.sched_getaffinity(0))
+            except AttributeError:
+                pass
+            n = args.cpu_sample_tiles or max(8, min(160, threads * 6))
+            cdt, tot = cpu_baseline(frame_np, sd, cs, ucs, ol, n, threads)
+            out["cpu_baseline"] = {
+                "value": round(mp * (n / tot) / cdt, 5),
+                "unit": "MP/s",
+                "cores": threads,
+                "kind": "port",
+                "sample": f"{n} of {tot} tiles of the same frame through oracle gather -> UtNet (torch CPU fp32, no_grad, "
+                          f"{threads} threads) -> stitch in {cdt:.2f} s, scaled by tiles",
+            }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

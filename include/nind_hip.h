@@ -1,0 +1,140 @@
+/* nind_hip.h -- C ABI of libnind_hip.so: the MI355X (gfx950) native tiled-denoise hot path.
+ *
+ * The reference (esq4/nind-denoise) is pure Python on torch and has NO native ABI; every entry point
+ * below therefore cites the reference Python interface it stands in for (paths relative to
+ * /root/reference/src/nind_denoise/).  The host side (the nind_denoise_amd Python package) binds these with ctypes;
+ * INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative nd_status on failure; nd_last_error() returns a
+ *     thread-local human-readable message for the last failure on the calling thread.
+ *   - device pointers are plain `void*`/`float*` into HBM owned by the caller (torch's caching allocator);
+ *     the library borrows them for the duration of the call, allocates nothing and frees nothing.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, no hidden synchronisation.
+ *   - images are float32 CHW (RGB), tiles are float32 NCHW, exactly as in the reference.
+ */
+#ifndef NIND_HIP_H
+#define NIND_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum nd_status {
+    ND_OK = 0,
+    ND_EINVAL = -1,   /* bad argument (e.g. cs not of the form 16k+56 for UtNet) */
+    ND_ENOMEM = -2,   /* workspace / output buffer too small                     */
+    ND_EHIP = -3      /* a HIP runtime call or kernel launch failed              */
+} nd_status;
+
+typedef enum nd_act {     /* UtNet.py:16-26 */
+    ND_ACT_NONE = 0,
+    ND_ACT_PRELU = 1,     /* one learned scalar slope per activation layer */
+    ND_ACT_ELU = 2,
+    ND_ACT_HARDSWISH = 3
+} nd_act;
+
+typedef enum nd_layer_kind {
+    ND_CONV3 = 0,         /* nn.Conv2d(k=3, valid)            UtNet.py:29..54          */
+    ND_CONVT3 = 1,        /* nn.ConvTranspose2d(k=3, s=1)     UtNet.py:56,61,63,...    */
+    ND_CONVT2S2 = 2,      /* nn.ConvTranspose2d(k=2, s=2)     UtNet.py:59,66,73,80     */
+    ND_CONV1 = 3          /* nn.Conv2d(k=1)                   UtNet.py:86              */
+} nd_layer_kind;
+
+typedef enum nd_dtype {
+    ND_F32 = 0            /* fp32 storage, fp32 MFMA (v_mfma_f32_32x32x2_f32), exact-fp32 products */
+} nd_dtype;
+
+int nd_version(void);
+const char *nd_last_error(void);
+
+/* ---------------------------------------------------------------- tile geometry (host, pure integer)
+ * OneImageDS.__init__   denoise_image.py:100-104  -> nd_tile_grid
+ * OneImageDS.__getitem__ denoise_image.py:131-143,172-173 -> nd_tile_geom
+ */
+int nd_tile_grid(int width, int height, int cs, int ucs, int ol, int *cols, int *rows, int *pad);
+int nd_tile_geom(int i, int width, int height, int cs, int ucs, int ol,
+                 int *x0, int *y0, int usefuldim[4], int usefulstart[2]);
+
+/* ---------------------------------------------------------------- device tiler
+ * nd_tile_gather: OneImageDS.__getitem__ (denoise_image.py:138-170) for tiles [tile_begin, tile_begin+tile_count):
+ *   crop + symmetric mirror padding, img_chw [3,H,W] -> tiles_nchw [tile_count,3,cs,cs].  Bit-exact copies.
+ * nd_stitch_add: main-loop body (denoise_image.py:249-267) + make_seamless_edges (:204-213):
+ *   canvas_chw [3,H,W] += halved-overlap useful crops of tiles_nchw, tiles taken in ascending index order
+ *   (same fp32 summation order as the reference).
+ */
+int nd_tile_gather(const float *img_chw, int width, int height, int cs, int ucs, int ol,
+                   int tile_begin, int tile_count, float *tiles_nchw, void *stream);
+int nd_stitch_add(float *canvas_chw, int width, int height, int cs, int ucs, int ol,
+                  const float *tiles_nchw, int tile_begin, int tile_count, void *stream);
+
+/* ---------------------------------------------------------------- UtNet (UtNet.py:13-109)
+ * Weight contract: the reference state-dict.  nd_utnet_num_tensors / nd_utnet_tensor_name
+ * enumerate the keys in the order nd_utnet_pack_weights expects host pointers (float32, contiguous, torch layout:
+ * Conv2d [Cout,Cin,k,k], ConvTranspose2d [Cin,Cout,k,k], bias [Cout], PReLU weight [1]).  For ELU/Hardswish the
+ * PReLU entries are absent from the state-dict; pass NULL for them.
+ * nn_common.Model.instantiate_model (nn_common.py:116-138) -> pack once at load time, upload, keep resident.
+ */
+int nd_utnet_num_tensors(void);
+const char *nd_utnet_tensor_name(int idx);
+size_t nd_utnet_packed_bytes(int funit, int dtype);
+int nd_utnet_pack_weights(int funit, int dtype, const float *const *tensors, int n_tensors,
+                          void *packed_host, size_t packed_bytes);
+
+/* Workspace for one (cs, batch) geometry: activations in the quad-planar layout, zero borders included.
+ * nd_utnet_workspace_init must run once on a workspace before its first forward with that geometry. */
+size_t nd_utnet_workspace_bytes(int funit, int cs, int batch, int dtype);
+int nd_utnet_workspace_init(void *workspace, size_t workspace_bytes, int funit, int cs, int batch, int dtype,
+                            void *stream);
+
+/* UtNet.forward (UtNet.py:97-109): x_nchw [batch,3,cs,cs] -> y_nchw [batch,3,cs,cs], both float32 in HBM. */
+int nd_utnet_forward(int funit, int act, int dtype, const void *packed_dev,
+                     const float *x_nchw, float *y_nchw, int batch, int cs,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* The whole hot loop of denoise_image.py:240-267 for tiles [tile_begin, tile_begin+tile_count) of one frame,
+ * device resident: gather(+mirror) -> UtNet -> useful crop -> seamless edges -> canvas +=.
+ * tile_count <= batch of the workspace.  Equivalent to nd_tile_gather + nd_utnet_forward + nd_stitch_add
+ * without materialising the NCHW tile batch. */
+int nd_utnet_denoise_tiles(int funit, int act, int dtype, const void *packed_dev,
+                           const float *img_chw, float *canvas_chw, int width, int height,
+                           int cs, int ucs, int ol, int tile_begin, int tile_count, int batch,
+                           void *workspace, size_t workspace_bytes, void *stream);
+
+/* Profiling entry point for the roofline report: one pass of the conv stack (22 MFMA conv launches + 4 pools, the
+ * launches between the input pack and the final 1x1) with a HIP event recorded on `stream` between launches.
+ * Synchronises the stream.  step_ms[i]: duration of launch i; step_flops[i]: its algorithmic FLOP for `batch` tiles
+ * (0 for pools); is_conv[i]: 1 for conv_qp_f32 launches.  nd_utnet_step_name(i): reference layer key. */
+int nd_utnet_profile_stack(int funit, int act, int dtype, const void *packed_dev, int batch, int cs,
+                           void *workspace, size_t workspace_bytes, void *stream,
+                           float *step_ms, double *step_flops, int *is_conv, int max_steps);
+const char *nd_utnet_step_name(int i);
+
+/* FLOP per tile by the reference's own accounting, for roofline reports. */
+double nd_utnet_flops(int funit, int cs);
+
+/* ---------------------------------------------------------------- single-layer entry points (parity tests)
+ * One weighted layer on NCHW float32 tensors: pack -> quad-planar conv kernel -> unpack.
+ * y = act(layer(x) + bias); output shape: CONV3 (H-2,W-2); CONVT3 (H+2,W+2); CONVT2S2 (2H,2W); CONV1 (H,W). */
+size_t nd_layer_packed_bytes(int kind, int cin, int cout, int dtype);
+int nd_layer_pack(int kind, int cin, int cout, int dtype, const float *weight, const float *bias,
+                  void *packed_host, size_t packed_bytes);
+size_t nd_layer_workspace_bytes(int kind, int batch, int cin, int cout, int h, int w, int dtype);
+int nd_layer_forward(int kind, int act, float slope, int dtype, const void *packed_dev,
+                     const float *x_nchw, int batch, int cin, int h, int w, int cout, float *y_nchw,
+                     void *workspace, size_t workspace_bytes, int variant, void *stream);
+/* nn.MaxPool2d(2) (UtNet.py:34) on NCHW float32 through the quad-planar pool kernel. */
+int nd_maxpool2_forward(const float *x_nchw, int batch, int c, int h, int w, float *y_nchw,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
+/* Name and average duration bookkeeping for bench.py: number of conv-kernel variants compiled in. */
+int nd_num_conv_variants(void);
+const char *nd_conv_variant_name(int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NIND_HIP_H */

@@ -1,0 +1,113 @@
+"""ctypes binding of libnind_hip.so (C ABI declared in include/nind_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnind_hip.so")
+
+ND_F32 = 0
+ACT = {"none": 0, "PReLU": 1, "ELU": 2, "Hardswish": 3}
+KIND = {"conv3": 0, "convT3": 1, "convT2s2": 2, "conv1": 3}
+
+
+class NindHipError(RuntimeError):
+    pass
+
+
+class NindHipMissing(ImportError):
+    pass
+
+
+_lib = None
+
+_SIGNATURES = {
+    "nd_version": (c_int, []),
+    "nd_last_error": (c_char_p, []),
+    "nd_tile_grid": (c_int, [c_int] * 5 + [POINTER(c_int)] * 3),
+    "nd_tile_geom": (c_int, [c_int] * 6 + [POINTER(c_int)] * 4),
+    "nd_tile_gather": (c_int, [c_void_p] + [c_int] * 7 + [c_void_p, c_void_p]),
+    "nd_stitch_add": (c_int, [c_void_p] + [c_int] * 5 + [c_void_p, c_int, c_int, c_void_p]),
+    "nd_utnet_num_tensors": (c_int, []),
+    "nd_utnet_tensor_name": (c_char_p, [c_int]),
+    "nd_utnet_packed_bytes": (c_size_t, [c_int, c_int]),
+    "nd_utnet_pack_weights": (c_int, [c_int, c_int, POINTER(c_void_p), c_int, c_void_p, c_size_t]),
+    "nd_utnet_workspace_bytes": (c_size_t, [c_int] * 4),
+    "nd_utnet_workspace_init": (c_int, [c_void_p, c_size_t] + [c_int] * 4 + [c_void_p]),
+    "nd_utnet_forward": (c_int, [c_int] * 3 + [c_void_p] * 3 + [c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "nd_utnet_denoise_tiles": (c_int, [c_int] * 3 + [c_void_p] * 3 + [c_int] * 8 + [c_void_p, c_size_t, c_void_p]),
+    "nd_utnet_flops": (c_double, [c_int, c_int]),
+    "nd_utnet_profile_stack": (c_int, [c_int] * 3 + [c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p,
+                                                      POINTER(c_float), POINTER(c_double), POINTER(c_int), c_int]),
+    "nd_utnet_step_name": (c_char_p, [c_int]),
+    "nd_layer_packed_bytes": (c_size_t, [c_int] * 4),
+    "nd_layer_pack": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_size_t]),
+    "nd_layer_workspace_bytes": (c_size_t, [c_int] * 7),
+    "nd_layer_forward": (c_int, [c_int, c_int, c_float, c_int, c_void_p, c_void_p] + [c_int] * 5
+                         + [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "nd_maxpool2_forward": (c_int, [c_void_p] + [c_int] * 4 + [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "nd_num_conv_variants": (c_int, []),
+    "nd_conv_variant_name": (c_char_p, [c_int]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises NindHipMissing when the library was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise NindHipMissing(
+            f"{LIB_PATH} not found: build it with `make -C nind_denoise_amd/csrc` (or __graft_entry__.build()). "
+            "nind_denoise_amd has no CPU fallback for the denoise hot path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().nd_last_error().decode(errors="replace")
+        exc = ValueError if rc == -1 else (MemoryError if rc == -2 else NindHipError)
+        raise exc(f"{what}: {msg}" if what else msg)
+
+
+def stream_ptr(device=None):
+    import torch
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    """Raw data pointer of a torch tensor (must be contiguous)."""
+    assert t.is_contiguous(), "tensor must be contiguous"
+    return c_void_p(t.data_ptr())
+
+
+# ---------------------------------------------------------------------------- host-only helpers
+
+def tile_grid(width, height, cs, ucs, ol):
+    cols, rows, pad = c_int(), c_int(), c_int()
+    check(load().nd_tile_grid(width, height, cs, ucs, ol, cols, rows, pad), "nd_tile_grid")
+    return cols.value, rows.value, pad.value
+
+
+def tile_geom(i, width, height, cs, ucs, ol):
+    x0, y0 = c_int(), c_int()
+    ud = (c_int * 4)()
+    us = (c_int * 2)()
+    check(load().nd_tile_geom(i, width, height, cs, ucs, ol, x0, y0, ud, us), "nd_tile_geom")
+    return x0.value, y0.value, tuple(ud), tuple(us)
+
+
+def utnet_tensor_names():
+    lib = load()
+    return [lib.nd_utnet_tensor_name(i).decode() for i in range(lib.nd_utnet_num_tensors())]

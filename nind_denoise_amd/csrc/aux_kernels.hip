@@ -1,0 +1,415 @@
+// HBM-bound helpers around the conv stack: tile geometry, tile gather (+mirror), stitch, layout conversion,
+// max-pool, the final 1x1 convolution.  All are pure copies / max / short dot products: the roofline that bounds them
+// is HBM bandwidth, so they read and write 16 B (or one full pixel row segment) per lane, coalesced along x.
+#include "nd_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------ tile geometry (OneImageDS, denoise_image.py:100-143)
+struct TileGeo {
+    int W, H, cs, ucs, ol, pad, stride, cols, rows;
+};
+
+static __host__ __device__ inline int ceil_div_py(int a, int b) {  // math.ceil(a / b) for b > 0, any sign of a
+    return a >= 0 ? (a + b - 1) / b : -((-a) / b);
+}
+
+static int make_geo(int W, int H, int cs, int ucs, int ol, TileGeo *g) {
+    if (W <= 0 || H <= 0 || cs <= 0 || ucs <= 0 || ol < 0) ND_FAIL(ND_EINVAL, "tile grid: non-positive size");
+    if (ucs - ol <= 0) ND_FAIL(ND_EINVAL, "tile grid: ucs (%d) must exceed the overlap (%d)", ucs, ol);
+    if (cs < ucs) ND_FAIL(ND_EINVAL, "tile grid: cs (%d) < ucs (%d)", cs, ucs);
+    g->W = W; g->H = H; g->cs = cs; g->ucs = ucs; g->ol = ol;
+    g->stride = ucs - ol;
+    g->pad = (cs - ucs) / 2;                                 // int((cs-ucs)/2), denoise_image.py:102
+    g->cols = ceil_div_py(W - ucs, g->stride) + 1;           // iperhl + 1, :101
+    g->rows = ceil_div_py(H - ucs, g->stride) + 1;           // ipervl + 1, :103
+    if (g->cols <= 0 || g->rows <= 0) ND_FAIL(ND_EINVAL, "tile grid: image %dx%d smaller than ucs=%d (undefined in the reference)", W, H, ucs);
+    // mirrored strips must come from inside the image (the reference's numpy slices fail otherwise)
+    const int x1pad = (g->cols - 1) * g->stride - g->pad + cs - W;
+    const int y1pad = (g->rows - 1) * g->stride - g->pad + cs - H;
+    if (g->pad > W || g->pad > H || x1pad > W || y1pad > H)
+        ND_FAIL(ND_EINVAL, "tile grid: mirror padding (%d,%d,%d) exceeds the image %dx%d", g->pad, x1pad, y1pad, W, H);
+    return ND_OK;
+}
+
+extern "C" int nd_tile_grid(int W, int H, int cs, int ucs, int ol, int *cols, int *rows, int *pad) {
+    TileGeo g;
+    ND_TRY(make_geo(W, H, cs, ucs, ol, &g));
+    if (cols) *cols = g.cols;
+    if (rows) *rows = g.rows;
+    if (pad) *pad = g.pad;
+    return ND_OK;
+}
+
+extern "C" int nd_tile_geom(int i, int W, int H, int cs, int ucs, int ol, int *x0, int *y0, int ud[4], int us[2]) {
+    TileGeo g;
+    ND_TRY(make_geo(W, H, cs, ucs, ol, &g));
+    if (i < 0 || i >= g.cols * g.rows) ND_FAIL(ND_EINVAL, "tile index %d outside [0,%d)", i, g.cols * g.rows);
+    const int yi = i / g.cols, xi = i - yi * g.cols;  // == int(ceil((i+1)/(iperhl+1) - 1)), :131-132
+    const int tx0 = xi * g.stride - g.pad, ty0 = yi * g.stride - g.pad;
+    const int x1pad = tx0 + cs - W > 0 ? tx0 + cs - W : 0;
+    const int y1pad = ty0 + cs - H > 0 ? ty0 + cs - H : 0;
+    if (x0) *x0 = tx0;
+    if (y0) *y0 = ty0;
+    if (ud) {
+        ud[0] = g.pad;
+        ud[1] = g.pad;
+        ud[2] = cs - (g.pad > x1pad ? g.pad : x1pad);
+        ud[3] = cs - (g.pad > y1pad ? g.pad : y1pad);
+    }
+    if (us) {
+        us[0] = tx0 + g.pad;
+        us[1] = ty0 + g.pad;
+    }
+    return ND_OK;
+}
+
+__device__ __forceinline__ int mirror_sym(int v, int n) {  // edge pixel repeated (np.flip of the adjacent band)
+    return v < 0 ? -1 - v : (v >= n ? 2 * n - 1 - v : v);
+}
+__device__ __forceinline__ int reflect_nr(int v, int n) {  // nn.ReflectionPad2d: edge pixel NOT repeated
+    return v < 0 ? -v : (v >= n ? 2 * (n - 1) - v : v);
+}
+
+// ------------------------------------------------------------------ gather: image CHW -> tiles NCHW
+__global__ void k_tile_gather(const float *__restrict__ img, TileGeo g, int tile_begin, float *__restrict__ out) {
+    const int xx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int yy = blockIdx.y;
+    const int t = blockIdx.z;
+    if (xx >= g.cs) return;
+    const int i = tile_begin + t;
+    const int yi = i / g.cols, xi = i - yi * g.cols;
+    const int sx = mirror_sym(xi * g.stride - g.pad + xx, g.W);
+    const int sy = mirror_sym(yi * g.stride - g.pad + yy, g.H);
+    const size_t plane = (size_t)g.W * g.H;
+    const size_t tplane = (size_t)g.cs * g.cs;
+    const float *s = img + (size_t)sy * g.W + sx;
+    float *d = out + ((size_t)t * 3) * tplane + (size_t)yy * g.cs + xx;
+    d[0] = s[0];
+    d[tplane] = s[plane];
+    d[2 * tplane] = s[2 * plane];
+}
+
+extern "C" int nd_tile_gather(const float *img, int W, int H, int cs, int ucs, int ol, int tile_begin, int tile_count,
+                              float *tiles, void *stream) {
+    TileGeo g;
+    ND_TRY(make_geo(W, H, cs, ucs, ol, &g));
+    if (tile_count == 0) return ND_OK;
+    if (!img || !tiles || tile_begin < 0 || tile_count < 0 || tile_begin + tile_count > g.cols * g.rows)
+        ND_FAIL(ND_EINVAL, "nd_tile_gather: tiles [%d,%d) outside the grid of %d", tile_begin, tile_begin + tile_count, g.cols * g.rows);
+    dim3 grid((cs + 255) / 256, cs, tile_count);
+    hipLaunchKernelGGL(k_tile_gather, grid, dim3(256), 0, (hipStream_t)stream, img, g, tile_begin, tiles);
+    ND_HIP(hipGetLastError());
+    return ND_OK;
+}
+
+// fused: gather(+symmetric mirror) -> ReflectionPad2d(2) -> quad-planar first-layer input (plane 0 = r,g,b,0)
+__global__ void k_gather_pack(const float *__restrict__ img, TileGeo g, int tile_begin, f32x4 *__restrict__ dst, int Sb) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;  // column in the reflect-padded tile
+    const int v = blockIdx.y;
+    const int t = blockIdx.z;
+    if (u >= Sb) return;
+    const int i = tile_begin + t;
+    const int yi = i / g.cols, xi = i - yi * g.cols;
+    const int qx = reflect_nr(u - 2, g.cs), qy = reflect_nr(v - 2, g.cs);
+    const int sx = mirror_sym(xi * g.stride - g.pad + qx, g.W);
+    const int sy = mirror_sym(yi * g.stride - g.pad + qy, g.H);
+    const size_t plane = (size_t)g.W * g.H;
+    const float *s = img + (size_t)sy * g.W + sx;
+    f32x4 o;
+    o[0] = s[0];
+    o[1] = s[plane];
+    o[2] = s[2 * plane];
+    o[3] = 0.f;
+    dst[((size_t)t * Sb + v) * Sb + u] = o;
+}
+
+int nd_launch_gather_pack(const float *img, int W, int H, int cs, int ucs, int ol, int tile_begin, int tile_count,
+                          const QpBuf &dst, hipStream_t s) {
+    TileGeo g;
+    ND_TRY(make_geo(W, H, cs, ucs, ol, &g));
+    if (tile_begin < 0 || tile_count <= 0 || tile_begin + tile_count > g.cols * g.rows || tile_count > dst.B)
+        ND_FAIL(ND_EINVAL, "gather_pack: bad tile range [%d,+%d)", tile_begin, tile_count);
+    if (dst.Hb != cs + 4 || dst.Wb != cs + 4 || dst.pad != 0) ND_FAIL(ND_EINVAL, "gather_pack: destination is not (cs+4)^2");
+    dim3 grid((cs + 4 + 255) / 256, cs + 4, tile_count);
+    hipLaunchKernelGGL(k_gather_pack, grid, dim3(256), 0, s, img, g, tile_begin, (f32x4 *)dst.base, cs + 4);
+    ND_HIP(hipGetLastError());
+    return ND_OK;
+}
+
+// ------------------------------------------------------------------ stitch (denoise_image.py:204-213, 249-267)
+// One thread per canvas pixel; contributions of the tiles [tile_begin, tile_begin+count) that cover it are added in
+// ascending tile index order on top of the current canvas value: the fp32 sum order of the reference's loop.
+struct Cover {
+    int t;      // tile index relative to tile_begin
+    int iy, ix; // position inside the tile
+    float f;    // 1, .5 or .25 (seamless edges)
+};
+
+template <typename F>
+__device__ __forceinline__ void for_each_cover(const TileGeo &g, int X, int Y, int tile_begin, int tile_count, F &&fn) {
+    const int uwmax = g.cs - 2 * g.pad;
+    int yi_lo = ceil_div_py(Y - uwmax + 1, g.stride);
+    if (yi_lo < 0) yi_lo = 0;
+    int yi_hi = Y / g.stride;
+    if (yi_hi > g.rows - 1) yi_hi = g.rows - 1;
+    int xi_lo = ceil_div_py(X - uwmax + 1, g.stride);
+    if (xi_lo < 0) xi_lo = 0;
+    int xi_hi = X / g.stride;
+    if (xi_hi > g.cols - 1) xi_hi = g.cols - 1;
+    for (int yi = yi_lo; yi <= yi_hi; ++yi) {
+        const int ay = yi * g.stride;
+        const int y1pad = max(0, ay - g.pad + g.cs - g.H);
+        const int uh = g.cs - max(g.pad, y1pad) - g.pad;
+        const int dy = Y - ay;
+        if (dy >= uh) continue;
+        float fy = 1.f;
+        if (ay != 0 && dy < g.ol) fy *= 0.5f;
+        if (ay + g.ucs < g.H && g.ol && dy >= uh - g.ol) fy *= 0.5f;
+        for (int xi = xi_lo; xi <= xi_hi; ++xi) {
+            const int i = yi * g.cols + xi;
+            if (i < tile_begin || i >= tile_begin + tile_count) continue;
+            const int ax = xi * g.stride;
+            const int x1pad = max(0, ax - g.pad + g.cs - g.W);
+            const int uw = g.cs - max(g.pad, x1pad) - g.pad;
+            const int dx = X - ax;
+            if (dx >= uw) continue;
+            float f = fy;
+            if (ax != 0 && dx < g.ol) f *= 0.5f;
+            if (ax + g.ucs < g.W && g.ol && dx >= uw - g.ol) f *= 0.5f;
+            fn(i - tile_begin, g.pad + dy, g.pad + dx, f);
+        }
+    }
+}
+
+__global__ void k_stitch_add(float *__restrict__ canvas, TileGeo g, const float *__restrict__ tiles, int tile_begin,
+                             int tile_count, int y_first) {
+    const int X = blockIdx.x * blockDim.x + threadIdx.x;
+    const int Y = y_first + blockIdx.y;
+    if (X >= g.W || Y >= g.H) return;
+    const size_t plane = (size_t)g.W * g.H;
+    const size_t tplane = (size_t)g.cs * g.cs;
+    float *c = canvas + (size_t)Y * g.W + X;
+    float v0 = c[0], v1 = c[plane], v2 = c[2 * plane];
+    bool any = false;
+    for_each_cover(g, X, Y, tile_begin, tile_count, [&](int t, int iy, int ix, float f) {
+        const float *s = tiles + (size_t)t * 3 * tplane + (size_t)iy * g.cs + ix;
+        v0 += s[0] * f;
+        v1 += s[tplane] * f;
+        v2 += s[2 * tplane] * f;
+        any = true;
+    });
+    if (any) {
+        c[0] = v0;
+        c[plane] = v1;
+        c[2 * plane] = v2;
+    }
+}
+
+static void stitch_band(const TileGeo &g, int tile_begin, int tile_count, int *y_first, int *y_rows) {
+    const int yi0 = tile_begin / g.cols, yi1 = (tile_begin + tile_count - 1) / g.cols;
+    const int uwmax = g.cs - 2 * g.pad;
+    int y0 = yi0 * g.stride, y1 = yi1 * g.stride + uwmax;
+    if (y1 > g.H) y1 = g.H;
+    *y_first = y0;
+    *y_rows = y1 - y0;
+}
+
+extern "C" int nd_stitch_add(float *canvas, int W, int H, int cs, int ucs, int ol, const float *tiles, int tile_begin,
+                             int tile_count, void *stream) {
+    TileGeo g;
+    ND_TRY(make_geo(W, H, cs, ucs, ol, &g));
+    if (tile_count == 0) return ND_OK;
+    if (!canvas || !tiles || tile_begin < 0 || tile_count < 0 || tile_begin + tile_count > g.cols * g.rows)
+        ND_FAIL(ND_EINVAL, "nd_stitch_add: tiles [%d,%d) outside the grid of %d", tile_begin, tile_begin + tile_count, g.cols * g.rows);
+    int yf, yr;
+    stitch_band(g, tile_begin, tile_count, &yf, &yr);
+    if (yr <= 0) return ND_OK;
+    dim3 grid((W + 255) / 256, yr);
+    hipLaunchKernelGGL(k_stitch_add, grid, dim3(256), 0, (hipStream_t)stream, canvas, g, tiles, tile_begin, tile_count, yf);
+    ND_HIP(hipGetLastError());
+    return ND_OK;
+}
+
+// ------------------------------------------------------------------ layout conversion NCHW <-> quad-planar
+__global__ void k_nchw_to_qp(const float *__restrict__ x, int C, int H, int W, f32x4 *__restrict__ dst, long np, int Hb,
+                             int Wb, int pad, int plane0) {
+    const int xx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int yy = blockIdx.y;
+    const int q = blockIdx.z % ((C + 3) / 4), b = blockIdx.z / ((C + 3) / 4);
+    if (xx >= W) return;
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = 4 * q + e;
+        o[e] = c < C ? x[(((size_t)b * C + c) * H + yy) * W + xx] : 0.f;
+    }
+    dst[(size_t)(plane0 + q) * np + ((size_t)b * Hb + yy + pad) * Wb + xx + pad] = o;
+}
+
+int nd_launch_nchw_to_qp(const float *x, int C, const QpBuf &dst, int plane0, hipStream_t s) {
+    const int H = dst.Hb - 2 * dst.pad, W = dst.Wb - 2 * dst.pad;
+    dim3 grid((W + 255) / 256, H, dst.B * ((C + 3) / 4));
+    hipLaunchKernelGGL(k_nchw_to_qp, grid, dim3(256), 0, s, x, C, H, W, (f32x4 *)dst.base, dst.np(), dst.Hb, dst.Wb,
+                       dst.pad, plane0);
+    ND_HIP(hipGetLastError());
+    return ND_OK;
+}
+
+__global__ void k_qp_to_nchw(const f32x4 *__restrict__ src, long np, int Hb, int Wb, int pad, int plane0,
+                             float *__restrict__ y, int C, int H, int W) {
+    const int xx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int yy = blockIdx.y;
+    const int q = blockIdx.z % ((C + 3) / 4), b = blockIdx.z / ((C + 3) / 4);
+    if (xx >= W) return;
+    const f32x4 v = src[(size_t)(plane0 + q) * np + ((size_t)b * Hb + yy + pad) * Wb + xx + pad];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = 4 * q + e;
+        if (c < C) y[(((size_t)b * C + c) * H + yy) * W + xx] = v[e];
+    }
+}
+
+int nd_launch_qp_to_nchw(const QpBuf &src, int plane0, float *y, int C, hipStream_t s) {
+    const int H = src.Hb - 2 * src.pad, W = src.Wb - 2 * src.pad;
+    dim3 grid((W + 255) / 256, H, src.B * ((C + 3) / 4));
+    hipLaunchKernelGGL(k_qp_to_nchw, grid, dim3(256), 0, s, (const f32x4 *)src.base, src.np(), src.Hb, src.Wb, src.pad,
+                       plane0, y, C, H, W);
+    ND_HIP(hipGetLastError());
+    return ND_OK;
+}
+
+// x [B,3,S,S] -> ReflectionPad2d(2) (UtNet.py:27,98) -> plane 0 of the first-layer input [(S+4)^2]
+__global__ void k_reflect_pack(const float *__restrict__ x, int S, f32x4 *__restrict__ dst) {
+    const int Sb = S + 4;
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    const int v = blockIdx.y, b = blockIdx.z;
+    if (u >= Sb) return;
+    const int qx = reflect_nr(u - 2, S), qy = reflect_nr(v - 2, S);
+    const float *s = x + ((size_t)b * 3 * S + qy) * S + qx;
+    f32x4 o;
+    o[0] = s[0];
+    o[1] = s[(size_t)S * S];
+    o[2] = s[2 * (size_t)S * S];
+    o[3] = 0.f;
+    dst[((size_t)b * Sb + v) * Sb + u] = o;
+}
+
+int nd_launch_reflect_pack(const float *x, int B, int S, const QpBuf &dst, hipStream_t s) {
+    if (dst.Hb != S + 4 || dst.Wb != S + 4 || dst.pad != 0 || B > dst.B) ND_FAIL(ND_EINVAL, "reflect_pack: bad destination");
+    dim3 grid((S + 4 + 255) / 256, S + 4, B);
+    hipLaunchKernelGGL(k_reflect_pack, grid, dim3(256), 0, s, x, S, (f32x4 *)dst.base);
+    ND_HIP(hipGetLastError());
+    return ND_OK;
+}
+
+// ------------------------------------------------------------------ MaxPool2d(2) (UtNet.py:34), quad-planar
+__global__ void k_maxpool2(const f32x4 *__restrict__ src, long snp, int sHb, int sWb, int spad, int splane0,
+                           f32x4 *__restrict__ dst, long dnp, int dHb, int dWb, int dpad, int Ho, int Wo, int B) {
+    const int xx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int yy = blockIdx.y;
+    const int b = blockIdx.z % B, q = blockIdx.z / B;
+    if (xx >= Wo) return;
+    const f32x4 *s = src + (size_t)(splane0 + q) * snp + ((size_t)b * sHb + 2 * yy + spad) * sWb + 2 * xx + spad;
+    const f32x4 a = s[0], c = s[1], d = s[sWb], e = s[sWb + 1];
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = fmaxf(fmaxf(a[k], c[k]), fmaxf(d[k], e[k]));
+    dst[(size_t)q * dnp + ((size_t)b * dHb + yy + dpad) * dWb + xx + dpad] = o;
+}
+
+int nd_launch_maxpool2(const QpBuf &src, int src_plane0, int planes, const QpBuf &dst, hipStream_t s) {
+    const int Hi = src.Hb - 2 * src.pad, Wi = src.Wb - 2 * src.pad;
+    const int Ho = Hi / 2, Wo = Wi / 2;
+    if (dst.Hb - 2 * dst.pad != Ho || dst.Wb - 2 * dst.pad != Wo || dst.B != src.B || dst.planes < planes)
+        ND_FAIL(ND_EINVAL, "maxpool2: destination does not fit %dx%d", Ho, Wo);
+    dim3 grid((Wo + 127) / 128, Ho, src.B * planes);
+    hipLaunchKernelGGL(k_maxpool2, grid, dim3(128), 0, s, (const f32x4 *)src.base, src.np(), src.Hb, src.Wb, src.pad,
+                       src_plane0, (f32x4 *)dst.base, dst.np(), dst.Hb, dst.Wb, dst.pad, Ho, Wo, src.B);
+    ND_HIP(hipGetLastError());
+    return ND_OK;
+}
+
+// ------------------------------------------------------------------ final Conv2d(funit,3,1) + ZeroPad2d(-2) (UtNet.py:86,88)
+// w: [3][cin] (torch layout), bias [3].  One thread per output pixel; each plane read is a coalesced float4 stream.
+__device__ __forceinline__ void dot3(const f32x4 *__restrict__ s, long np, int planes, const float *__restrict__ w,
+                                     int cin, float &o0, float &o1, float &o2) {
+    for (int q = 0; q < planes; ++q) {
+        const f32x4 v = s[(size_t)q * np];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * q + e;
+            if (c < cin) {
+                o0 = fmaf(v[e], w[c], o0);
+                o1 = fmaf(v[e], w[cin + c], o1);
+                o2 = fmaf(v[e], w[2 * cin + c], o2);
+            }
+        }
+    }
+}
+
+__global__ void k_final1x1(const f32x4 *__restrict__ src, long np, int Hb, int Wb, int planes, int cin,
+                           const float *__restrict__ w, const float *__restrict__ bias, int crop, float *__restrict__ y,
+                           int S) {
+    const int xx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int yy = blockIdx.y, b = blockIdx.z;
+    if (xx >= S) return;
+    float o0 = bias[0], o1 = bias[1], o2 = bias[2];
+    dot3(src + ((size_t)b * Hb + yy + crop) * Wb + xx + crop, np, planes, w, cin, o0, o1, o2);
+    float *d = y + ((size_t)b * 3 * S + yy) * S + xx;
+    d[0] = o0;
+    d[(size_t)S * S] = o1;
+    d[2 * (size_t)S * S] = o2;
+}
+
+int nd_launch_final1x1(const QpBuf &src, int cin, const float *w, const float *bias, int crop, float *y, int S,
+                       hipStream_t s) {
+    if (src.pad != 0 || src.Hb != S + 2 * crop || src.Wb != S + 2 * crop) ND_FAIL(ND_EINVAL, "final1x1: bad source geometry");
+    dim3 grid((S + 255) / 256, S, src.B);
+    hipLaunchKernelGGL(k_final1x1, grid, dim3(256), 0, s, (const f32x4 *)src.base, src.np(), src.Hb, src.Wb,
+                       (cin + 3) / 4, cin, w, bias, crop, y, S);
+    ND_HIP(hipGetLastError());
+    return ND_OK;
+}
+
+// fused: final 1x1 + crop + useful crop + seamless edges + canvas += (no NCHW tile batch in HBM)
+__global__ void k_final1x1_stitch(const f32x4 *__restrict__ src, long np, int Hb, int Wb, int planes, int cin,
+                                  const float *__restrict__ w, const float *__restrict__ bias, int crop,
+                                  float *__restrict__ canvas, TileGeo g, int tile_begin, int tile_count, int y_first) {
+    const int X = blockIdx.x * blockDim.x + threadIdx.x;
+    const int Y = y_first + blockIdx.y;
+    if (X >= g.W || Y >= g.H) return;
+    const size_t plane = (size_t)g.W * g.H;
+    float *c = canvas + (size_t)Y * g.W + X;
+    float v0 = c[0], v1 = c[plane], v2 = c[2 * plane];
+    bool any = false;
+    for_each_cover(g, X, Y, tile_begin, tile_count, [&](int t, int iy, int ix, float f) {
+        float o0 = bias[0], o1 = bias[1], o2 = bias[2];
+        dot3(src + ((size_t)t * Hb + iy + crop) * Wb + ix + crop, np, planes, w, cin, o0, o1, o2);
+        v0 += o0 * f;
+        v1 += o1 * f;
+        v2 += o2 * f;
+        any = true;
+    });
+    if (any) {
+        c[0] = v0;
+        c[plane] = v1;
+        c[2 * plane] = v2;
+    }
+}
+
+int nd_launch_final1x1_stitch(const QpBuf &src, int cin, const float *w, const float *bias, int crop, float *canvas,
+                              int W, int H, int cs, int ucs, int ol, int tile_begin, int tile_count, hipStream_t s) {
+    TileGeo g;
+    ND_TRY(make_geo(W, H, cs, ucs, ol, &g));
+    if (src.pad != 0 || src.Hb != cs + 2 * crop || src.Wb != cs + 2 * crop || tile_count > src.B)
+        ND_FAIL(ND_EINVAL, "final1x1_stitch: bad source geometry");
+    int yf, yr;
+    stitch_band(g, tile_begin, tile_count, &yf, &yr);
+    if (yr <= 0) return ND_OK;
+    dim3 grid((W + 255) / 256, yr);
+    hipLaunchKernelGGL(k_final1x1_stitch, grid, dim3(256), 0, s, (const f32x4 *)src.base, src.np(), src.Hb, src.Wb,
+                       (cin + 3) / 4, cin, w, bias, crop, canvas, g, tile_begin, tile_count, yf);
+    ND_HIP(hipGetLastError());
+    return ND_OK;
+}

@@ -1,0 +1,83 @@
+// Host-side weight repacking: torch state-dict tensors -> MFMA "A"-fragment order (done once at model load;
+// reference load path: nn_common.py:127-132 `load_state_dict(torch.load(path))`).
+//
+// Packed layer = [mtile][kb][tap][lane 0..63][4 floats]  followed by  bias[mtiles*32]
+//   lane = 32*h + i supplies rows m = 32*mtile + i and channels ci = 8*kb + 4*h + s (s = 0..3)
+//   value = Weff[m][ci][tap]:
+//     CONV3    Weff[co][ci][(ky,kx)] = w[co][ci][ky][kx]                         (w: [Cout,Cin,3,3])
+//     CONVT3   Weff[co][ci][(a,b)]   = w[ci][co][2-a][2-b]                       (w: [Cin,Cout,3,3]; spatial flip +
+//                                                                                  channel transpose turn the transpose
+//                                                                                  conv into a correlation on the
+//                                                                                  zero-bordered input)
+//     CONVT2S2 Weff[(a,b,co)][ci]    = w[ci][co][a][b],  m = (2a+b)*Cout + co     (w: [Cin,Cout,2,2])
+//     CONV1    Weff[co][ci]          = w[co][ci]
+#include <string.h>
+
+#include "nd_common.h"
+
+static thread_local char g_err[512] = "";
+
+void nd_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *nd_last_error(void) { return g_err; }
+extern "C" int nd_version(void) { return 100; }
+
+void nd_pack_layer_f32(int kind, int cin, int cout, const float *w, const float *bias, float *packed) {
+    const int taps = nd_taps(kind);
+    const int KB = nd_kblocks(cin);
+    const int MT = nd_mtiles(kind, cout);
+    const int M = kind == ND_CONVT2S2 ? 4 * cout : cout;
+    float *bp = packed + (size_t)MT * KB * taps * 256;
+    for (int mt = 0; mt < MT; ++mt)
+        for (int kb = 0; kb < KB; ++kb)
+            for (int t = 0; t < taps; ++t) {
+                float *dst = packed + (((size_t)mt * KB + kb) * taps + t) * 256;
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int i = lane & 31, h = lane >> 5;
+                    const int m = 32 * mt + i;
+                    for (int s = 0; s < 4; ++s) {
+                        const int ci = 8 * kb + 4 * h + s;
+                        float v = 0.f;
+                        if (m < M && ci < cin) {
+                            switch (kind) {
+                                case ND_CONV3: v = w[((size_t)m * cin + ci) * 9 + t]; break;
+                                case ND_CONVT3: v = w[((size_t)ci * cout + m) * 9 + (8 - t)]; break;
+                                case ND_CONVT2S2: {
+                                    const int ab = m / cout, co = m - ab * cout;
+                                    v = w[((size_t)ci * cout + co) * 4 + ab];
+                                    break;
+                                }
+                                default: v = w[(size_t)m * cin + ci]; break;
+                            }
+                        }
+                        dst[lane * 4 + s] = v;
+                    }
+                }
+            }
+    for (int m = 0; m < MT * 32; ++m) {
+        float v = 0.f;
+        if (m < M && bias) v = bias[kind == ND_CONVT2S2 ? m % cout : m];
+        bp[m] = v;
+    }
+}
+
+extern "C" size_t nd_layer_packed_bytes(int kind, int cin, int cout, int dtype) {
+    if (dtype != ND_F32 || kind < 0 || kind > 3 || cin <= 0 || cout <= 0) return 0;
+    return nd_packed_floats(kind, cin, cout) * sizeof(float);
+}
+
+extern "C" int nd_layer_pack(int kind, int cin, int cout, int dtype, const float *weight, const float *bias,
+                             void *packed_host, size_t packed_bytes) {
+    if (dtype != ND_F32) ND_FAIL(ND_EINVAL, "nd_layer_pack: unsupported dtype %d", dtype);
+    if (kind < 0 || kind > 3 || cin <= 0 || cout <= 0 || !weight || !packed_host)
+        ND_FAIL(ND_EINVAL, "nd_layer_pack: bad arguments");
+    if (packed_bytes < nd_layer_packed_bytes(kind, cin, cout, dtype))
+        ND_FAIL(ND_ENOMEM, "nd_layer_pack: packed buffer too small");
+    nd_pack_layer_f32(kind, cin, cout, weight, bias, (float *)packed_host);
+    return ND_OK;
+}

@@ -1,0 +1,483 @@
+// UtNet executor: static buffer plan per (funit, cs, batch), every layer enqueued on one stream.
+// Reference: networks/UtNet.py:27-88 (layers), :97-109 (forward).  The concats of forward() are zero-copy: the
+// up-sampling layer and the encoder skip both write straight into their halves of one bordered buffer
+// (up-sampled channels FIRST, skip second -- UtNet.py:103-106).
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "nd_common.h"
+
+namespace {
+
+struct LayerSpec {
+    const char *key;
+    int kind;
+    int cin_mul, cout_mul;  // channels = mul * funit (cin_mul 0 -> 3 input channels, cout_mul 0 -> 3 output channels)
+    int prelu;              // index into the slope table, -1: no activation
+};
+
+// forward order; prelu indices follow the state-dict order of the activation modules
+const LayerSpec kLayers[] = {
+    {"convs1.0", ND_CONV3, 0, 1, 0},    {"convs1.2", ND_CONV3, 1, 1, 1},    {"convs2.0", ND_CONV3, 1, 2, 2},
+    {"convs2.2", ND_CONV3, 2, 2, 3},    {"convs3.0", ND_CONV3, 2, 4, 4},    {"convs3.2", ND_CONV3, 4, 4, 5},
+    {"convs4.0", ND_CONV3, 4, 8, 6},    {"convs4.2", ND_CONV3, 8, 8, 7},    {"bottom.0", ND_CONV3, 8, 16, 8},
+    {"bottom.2", ND_CONVT3, 16, 16, 9}, {"up1", ND_CONVT2S2, 16, 8, -1},    {"tconvs1.0", ND_CONVT3, 16, 8, 10},
+    {"tconvs1.2", ND_CONVT3, 8, 8, 11}, {"up2", ND_CONVT2S2, 8, 4, -1},     {"tconvs2.0", ND_CONVT3, 8, 4, 12},
+    {"tconvs2.2", ND_CONVT3, 4, 4, 13}, {"up3", ND_CONVT2S2, 4, 2, -1},     {"tconvs3.0", ND_CONVT3, 4, 2, 14},
+    {"tconvs3.2", ND_CONVT3, 2, 2, 15}, {"up4", ND_CONVT2S2, 2, 1, -1},     {"tconvs4.0", ND_CONVT3, 2, 1, 16},
+    {"tconvs4.2", ND_CONVT3, 1, 1, 17}, {"tconvs4.4", ND_CONV1, 1, 0, -1},
+};
+constexpr int kNumLayers = (int)(sizeof(kLayers) / sizeof(kLayers[0]));
+constexpr int kNumSlopes = 18;
+constexpr int kHeaderFloats = 32;  // slope table (18 used)
+
+// state-dict order of the reference module (UtNet.py:27-88): weight, bias of every layer, PReLU weights interleaved
+std::vector<std::string> build_tensor_names() {
+    std::vector<std::string> n;
+    auto seq = [&](const std::string &p, int n_act_pairs, bool final1x1) {
+        for (int k = 0; k < n_act_pairs; ++k) {
+            n.push_back(p + "." + std::to_string(2 * k) + ".weight");
+            n.push_back(p + "." + std::to_string(2 * k) + ".bias");
+            n.push_back(p + "." + std::to_string(2 * k + 1) + ".weight");
+        }
+        if (final1x1) {
+            n.push_back(p + ".4.weight");
+            n.push_back(p + ".4.bias");
+        }
+    };
+    for (int i = 1; i <= 4; ++i) seq("convs" + std::to_string(i), 2, false);
+    seq("bottom", 2, false);
+    for (int i = 1; i <= 4; ++i) {
+        n.push_back("up" + std::to_string(i) + ".weight");
+        n.push_back("up" + std::to_string(i) + ".bias");
+        seq("tconvs" + std::to_string(i), 2, i == 4);
+    }
+    return n;
+}
+const std::vector<std::string> &tensor_names() {
+    static const std::vector<std::string> n = build_tensor_names();
+    return n;
+}
+int tensor_index(const std::string &name) {
+    const auto &n = tensor_names();
+    for (size_t i = 0; i < n.size(); ++i)
+        if (n[i] == name) return (int)i;
+    return -1;
+}
+
+inline int lcin(const LayerSpec &l, int f) { return l.cin_mul ? l.cin_mul * f : 3; }
+inline int lcout(const LayerSpec &l, int f) { return l.cout_mul ? l.cout_mul * f : 3; }
+
+// float offsets of every layer inside the packed blob
+struct BlobLayout {
+    size_t off[kNumLayers];
+    size_t total;
+};
+BlobLayout blob_layout(int f) {
+    BlobLayout b;
+    size_t o = kHeaderFloats;
+    for (int i = 0; i < kNumLayers; ++i) {
+        b.off[i] = o;
+        const LayerSpec &l = kLayers[i];
+        if (i == kNumLayers - 1)
+            o += ((size_t)3 * lcin(l, f) + 3 + 3) / 4 * 4;  // raw [3][cin] + bias[3] for the VALU 1x1 kernel
+        else
+            o += nd_packed_floats(l.kind, lcin(l, f), lcout(l, f));
+    }
+    b.total = o;
+    return b;
+}
+
+bool valid_cs(int cs) { return cs >= 104 && (cs - 56) % 16 == 0; }
+
+int check_net(int funit, int cs, int batch, int dtype) {
+    if (dtype != ND_F32) ND_FAIL(ND_EINVAL, "UtNet: unsupported dtype %d", dtype);
+    if (funit < 8 || funit % 8) ND_FAIL(ND_EINVAL, "UtNet: funit=%d must be a positive multiple of 8", funit);
+    if (!valid_cs(cs))
+        ND_FAIL(ND_EINVAL, "UtNet: tile size cs=%d is not of the form 16k+56 (104, 120, ..., 248, 264, ..., 504, 520); "
+                           "the reference network rejects it too (sizes of the skip concats do not match)", cs);
+    if (batch <= 0) ND_FAIL(ND_EINVAL, "UtNet: batch=%d", batch);
+    return ND_OK;
+}
+
+// ---------------------------------------------------------------- workspace plan
+enum Buf { X0, A1, CAT4, P1, A2, CAT3, P2, A3, CAT2, P3, A4, CAT1, P4, BT0, BT1, T1A, T1B, T2A, T2B, T3A, T3B, T4A, T4B, NBUF };
+
+struct Plan {
+    QpBuf buf[NBUF];
+    size_t bytes;
+};
+
+// cap = batch the workspace was sized for; nimg = images in use (<= cap)
+Plan make_plan(int f, int cs, int cap, int nimg, char *base) {
+    Plan p;
+    size_t off = 0;
+    auto add = [&](Buf id, int ch, int size, int pad) {
+        QpBuf &q = p.buf[id];
+        q.planes = (ch + 3) / 4;
+        if (id == X0) q.planes = 2;
+        q.B = nimg;
+        q.Hb = q.Wb = size + 2 * pad;
+        q.pad = pad;
+        q.pstride = (long)cap * q.Hb * q.Wb;
+        q.base = (float *)(base + off);
+        // slack: an N tile may read (tile + 3x3 halo) pixels past the last plane
+        const size_t slack = (size_t)(2 * q.Wb + 2 + 512 + 64);
+        off += ((size_t)q.planes * q.pstride + slack) * 16;
+        off = (off + 255) & ~(size_t)255;
+    };
+    const int l1 = cs, l2 = cs / 2 - 4, l3 = l2 / 2 - 4, l4 = l3 / 2 - 4, p4 = l4 / 2;
+    add(X0, 8, cs + 4, 0);
+    add(A1, f, cs + 2, 0);
+    add(CAT4, 2 * f, l1, 2);
+    add(P1, f, l1 / 2, 0);
+    add(A2, 2 * f, l1 / 2 - 2, 0);
+    add(CAT3, 4 * f, l2, 2);
+    add(P2, 2 * f, l2 / 2, 0);
+    add(A3, 4 * f, l2 / 2 - 2, 0);
+    add(CAT2, 8 * f, l3, 2);
+    add(P3, 4 * f, l3 / 2, 0);
+    add(A4, 8 * f, l3 / 2 - 2, 0);
+    add(CAT1, 16 * f, l4, 2);
+    add(P4, 8 * f, p4, 0);
+    add(BT0, 16 * f, p4 - 2, 2);
+    add(BT1, 16 * f, p4, 0);
+    add(T1A, 8 * f, l4 + 2, 2);
+    add(T1B, 8 * f, l4 + 4, 0);
+    add(T2A, 4 * f, l3 + 2, 2);
+    add(T2B, 4 * f, l3 + 4, 0);
+    add(T3A, 2 * f, l2 + 2, 2);
+    add(T3B, 2 * f, l2 + 4, 0);
+    add(T4A, f, l1 + 2, 2);
+    add(T4B, f, l1 + 4, 0);
+    p.bytes = off;
+    return p;
+}
+
+struct Step {
+    int layer;  // index into kLayers, or -1 for a pool
+    Buf src, dst;
+    int dst_plane0_mul;  // destination plane offset = mul * funit / 4
+};
+// the conv stack between the input pack and the final 1x1 (UtNet.py:99-107)
+constexpr int kNumSteps = 26;
+const Step kSteps[kNumSteps] = {
+    {0, X0, A1, 0},     {1, A1, CAT4, 1},   {-1, CAT4, P1, 1},  {2, P1, A2, 0},    {3, A2, CAT3, 2},  {-1, CAT3, P2, 2},
+    {4, P2, A3, 0},     {5, A3, CAT2, 4},   {-1, CAT2, P3, 4},  {6, P3, A4, 0},    {7, A4, CAT1, 8},  {-1, CAT1, P4, 8},
+    {8, P4, BT0, 0},    {9, BT0, BT1, 0},   {10, BT1, CAT1, 0}, {11, CAT1, T1A, 0}, {12, T1A, T1B, 0}, {13, T1B, CAT2, 0},
+    {14, CAT2, T2A, 0}, {15, T2A, T2B, 0},  {16, T2B, CAT3, 0}, {17, CAT3, T3A, 0}, {18, T3A, T3B, 0}, {19, T3B, CAT4, 0},
+    {20, CAT4, T4A, 0}, {21, T4A, T4B, 0},
+};
+
+// ev (optional): kNumSteps+1 events, ev[i] recorded before step i, ev[kNumSteps] after the last one
+int run_stack(int f, int act, const float *blob, const Plan &pl, hipStream_t s, hipEvent_t *ev = nullptr) {
+    const BlobLayout bl = blob_layout(f);
+    int si = 0;
+    for (const Step &st : kSteps) {
+        if (ev) ND_HIP(hipEventRecord(ev[si], s));
+        ++si;
+        if (st.layer < 0) {
+            // pool reads the skip half of the concat buffer: planes [mul*f/4, 2*mul*f/4)
+            ND_TRY(nd_launch_maxpool2(pl.buf[st.src], st.dst_plane0_mul * f / 4, st.dst_plane0_mul * f / 4, pl.buf[st.dst], s));
+            continue;
+        }
+        const LayerSpec &l = kLayers[st.layer];
+        ConvDesc d;
+        d.kind = l.kind;
+        d.act = l.prelu >= 0 ? act : ND_ACT_NONE;
+        d.slope = 0.25f;
+        d.slope_dev = (l.prelu >= 0 && act == ND_ACT_PRELU) ? blob + l.prelu : nullptr;
+        d.cin = lcin(l, f);
+        d.cout = lcout(l, f);
+        d.wpk = blob + bl.off[st.layer];
+        d.bias = d.wpk + (size_t)nd_mtiles(l.kind, d.cout) * nd_kblocks(d.cin) * nd_taps(l.kind) * 256;
+        d.in = pl.buf[st.src];
+        d.out = pl.buf[st.dst];
+        d.out_plane0 = st.dst_plane0_mul * f / 4;
+        d.variant = -1;
+        ND_TRY(nd_launch_conv_f32(d, s));
+    }
+    if (ev) ND_HIP(hipEventRecord(ev[si], s));
+    return ND_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ C ABI
+extern "C" int nd_utnet_num_tensors(void) { return (int)tensor_names().size(); }
+extern "C" const char *nd_utnet_tensor_name(int idx) {
+    const auto &n = tensor_names();
+    return (idx >= 0 && idx < (int)n.size()) ? n[idx].c_str() : nullptr;
+}
+
+extern "C" size_t nd_utnet_packed_bytes(int funit, int dtype) {
+    if (dtype != ND_F32 || funit < 8 || funit % 8) return 0;
+    return blob_layout(funit).total * sizeof(float);
+}
+
+extern "C" int nd_utnet_pack_weights(int funit, int dtype, const float *const *tensors, int n_tensors, void *packed_host,
+                                     size_t packed_bytes) {
+    if (dtype != ND_F32) ND_FAIL(ND_EINVAL, "nd_utnet_pack_weights: unsupported dtype %d", dtype);
+    if (funit < 8 || funit % 8) ND_FAIL(ND_EINVAL, "nd_utnet_pack_weights: funit=%d must be a positive multiple of 8", funit);
+    if (n_tensors != nd_utnet_num_tensors()) ND_FAIL(ND_EINVAL, "nd_utnet_pack_weights: expected %d tensors, got %d", nd_utnet_num_tensors(), n_tensors);
+    const BlobLayout bl = blob_layout(funit);
+    if (packed_bytes < bl.total * sizeof(float)) ND_FAIL(ND_ENOMEM, "nd_utnet_pack_weights: packed buffer too small");
+    float *blob = (float *)packed_host;
+    memset(blob, 0, bl.total * sizeof(float));
+    for (int i = 0; i < kNumLayers; ++i) {
+        const LayerSpec &l = kLayers[i];
+        const int wi = tensor_index(std::string(l.key) + ".weight"), bi = tensor_index(std::string(l.key) + ".bias");
+        if (wi < 0 || bi < 0 || !tensors[wi] || !tensors[bi]) ND_FAIL(ND_EINVAL, "nd_utnet_pack_weights: missing tensor %s.{weight,bias}", l.key);
+        const int ci = lcin(l, funit), co = lcout(l, funit);
+        if (i == kNumLayers - 1) {
+            memcpy(blob + bl.off[i], tensors[wi], sizeof(float) * 3 * ci);
+            memcpy(blob + bl.off[i] + 3 * ci, tensors[bi], sizeof(float) * 3);
+        } else {
+            nd_pack_layer_f32(l.kind, ci, co, tensors[wi], tensors[bi], blob + bl.off[i]);
+        }
+        if (l.prelu >= 0) {
+            // activation module sits right after the layer in its Sequential: "<seq>.<k+1>.weight"
+            std::string k(l.key);
+            const size_t dot = k.rfind('.');
+            const std::string an = k.substr(0, dot + 1) + std::to_string(atoi(k.c_str() + dot + 1) + 1) + ".weight";
+            const int ai = tensor_index(an);
+            blob[l.prelu] = (ai >= 0 && tensors[ai]) ? tensors[ai][0] : 0.25f;
+        }
+    }
+    return ND_OK;
+}
+
+extern "C" size_t nd_utnet_workspace_bytes(int funit, int cs, int batch, int dtype) {
+    if (check_net(funit, cs, batch, dtype) != ND_OK) return 0;
+    return make_plan(funit, cs, batch, batch, nullptr).bytes;
+}
+
+extern "C" int nd_utnet_workspace_init(void *ws, size_t ws_bytes, int funit, int cs, int batch, int dtype, void *stream) {
+    ND_TRY(check_net(funit, cs, batch, dtype));
+    const size_t need = make_plan(funit, cs, batch, batch, nullptr).bytes;
+    if (!ws || ws_bytes < need) ND_FAIL(ND_ENOMEM, "UtNet workspace: %zu B given, %zu B needed", ws_bytes, need);
+    // zero borders (the implicit padding of the transpose convolutions), the unused input channel plane and the slack
+    ND_HIP(hipMemsetAsync(ws, 0, need, (hipStream_t)stream));
+    return ND_OK;
+}
+
+static int forward_common(int funit, int act, int dtype, const void *packed, int batch_cap, int nimg, int cs, void *ws,
+                          size_t ws_bytes, Plan *out_plan) {
+    ND_TRY(check_net(funit, cs, batch_cap, dtype));
+    if (act < ND_ACT_PRELU || act > ND_ACT_HARDSWISH) ND_FAIL(ND_EINVAL, "UtNet: unknown activation %d", act);
+    if (nimg <= 0 || nimg > batch_cap) ND_FAIL(ND_EINVAL, "UtNet: %d images with a workspace batch of %d", nimg, batch_cap);
+    if (!packed || !ws) ND_FAIL(ND_EINVAL, "UtNet: null pointer");
+    if (((uintptr_t)ws & 15) || ((uintptr_t)packed & 15)) ND_FAIL(ND_EINVAL, "UtNet: workspace / weights must be 16-byte aligned");
+    *out_plan = make_plan(funit, cs, batch_cap, nimg, (char *)ws);
+    if (ws_bytes < out_plan->bytes) ND_FAIL(ND_ENOMEM, "UtNet workspace: %zu B given, %zu B needed", ws_bytes, out_plan->bytes);
+    return ND_OK;
+}
+
+extern "C" int nd_utnet_forward(int funit, int act, int dtype, const void *packed, const float *x, float *y, int batch,
+                                int cs, void *ws, size_t ws_bytes, void *stream) {
+    Plan pl;
+    ND_TRY(forward_common(funit, act, dtype, packed, batch, batch, cs, ws, ws_bytes, &pl));
+    if (!x || !y) ND_FAIL(ND_EINVAL, "UtNet: null tensor");
+    hipStream_t s = (hipStream_t)stream;
+    const float *blob = (const float *)packed;
+    ND_TRY(nd_launch_reflect_pack(x, batch, cs, pl.buf[X0], s));
+    ND_TRY(run_stack(funit, act, blob, pl, s));
+    const BlobLayout bl = blob_layout(funit);
+    const float *fw = blob + bl.off[kNumLayers - 1];
+    ND_TRY(nd_launch_final1x1(pl.buf[T4B], funit, fw, fw + 3 * funit, 2, y, cs, s));
+    return ND_OK;
+}
+
+extern "C" int nd_utnet_denoise_tiles(int funit, int act, int dtype, const void *packed, const float *img, float *canvas,
+                                      int width, int height, int cs, int ucs, int ol, int tile_begin, int tile_count,
+                                      int batch, void *ws, size_t ws_bytes, void *stream) {
+    Plan pl;
+    ND_TRY(forward_common(funit, act, dtype, packed, batch, tile_count, cs, ws, ws_bytes, &pl));
+    if (!img || !canvas) ND_FAIL(ND_EINVAL, "UtNet: null image");
+    hipStream_t s = (hipStream_t)stream;
+    const float *blob = (const float *)packed;
+    ND_TRY(nd_launch_gather_pack(img, width, height, cs, ucs, ol, tile_begin, tile_count, pl.buf[X0], s));
+    ND_TRY(run_stack(funit, act, blob, pl, s));
+    const BlobLayout bl = blob_layout(funit);
+    const float *fw = blob + bl.off[kNumLayers - 1];
+    ND_TRY(nd_launch_final1x1_stitch(pl.buf[T4B], funit, fw, fw + 3 * funit, 2, canvas, width, height, cs, ucs, ol,
+                                     tile_begin, tile_count, s));
+    return ND_OK;
+}
+
+// Profiling entry point (bench.py roofline leg): one forward of the conv stack with a HIP event between every launch
+// on `stream`.  Synchronises the stream.  step_ms[i] = duration of launch i (26 entries: 22 MFMA conv launches and
+// 4 pools, forward order); step_flops[i] = algorithmic FLOP of that launch (0 for pools), SURVEY.md 2a convention.
+extern "C" int nd_utnet_profile_stack(int funit, int act, int dtype, const void *packed, int batch, int cs, void *ws,
+                                      size_t ws_bytes, void *stream, float *step_ms, double *step_flops, int *is_conv,
+                                      int max_steps) {
+    Plan pl;
+    ND_TRY(forward_common(funit, act, dtype, packed, batch, batch, cs, ws, ws_bytes, &pl));
+    if (max_steps < kNumSteps || !step_ms) ND_FAIL(ND_EINVAL, "nd_utnet_profile_stack: need room for %d steps", kNumSteps);
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t ev[kNumSteps + 1];
+    for (auto &e : ev) ND_HIP(hipEventCreate(&e));
+    int rc = run_stack(funit, act, (const float *)packed, pl, s, ev);
+    if (rc == ND_OK) {
+        hipError_t e = hipStreamSynchronize(s);
+        if (e != hipSuccess) {
+            nd_set_error("hipStreamSynchronize failed: %s", hipGetErrorString(e));
+            rc = ND_EHIP;
+        }
+    }
+    for (int i = 0; i < kNumSteps && rc == ND_OK; ++i) {
+        if (hipEventElapsedTime(&step_ms[i], ev[i], ev[i + 1]) != hipSuccess) {
+            nd_set_error("hipEventElapsedTime failed");
+            rc = ND_EHIP;
+        }
+        const Step &st = kSteps[i];
+        double fl = 0;
+        if (st.layer >= 0) {
+            const LayerSpec &l = kLayers[st.layer];
+            const QpBuf &in = pl.buf[st.src];
+            const double ci = lcin(l, funit), co = lcout(l, funit);
+            const double hin = in.Hb - 2 * in.pad, win = in.Wb - 2 * in.pad;
+            switch (l.kind) {
+                case ND_CONV3: fl = 2.0 * (hin - 2) * (win - 2) * ci * co * 9; break;
+                case ND_CONVT3: fl = 2.0 * hin * win * ci * co * 9; break;
+                case ND_CONVT2S2: fl = 2.0 * hin * win * ci * co * 4; break;
+                default: fl = 2.0 * hin * win * ci * co; break;
+            }
+            fl *= batch;
+        }
+        if (step_flops) step_flops[i] = fl;
+        if (is_conv) is_conv[i] = st.layer >= 0;
+    }
+    for (auto &e : ev) hipEventDestroy(e);
+    return rc;
+}
+
+extern "C" const char *nd_utnet_step_name(int i) {
+    if (i < 0 || i >= kNumSteps) return nullptr;
+    return kSteps[i].layer >= 0 ? kLayers[kSteps[i].layer].key : "maxpool";
+}
+
+extern "C" double nd_utnet_flops(int funit, int cs) {
+    if (!valid_cs(cs) || funit <= 0) return 0.0;
+    const double f = funit;
+    double mac = 0;
+    int h = cs + 4;
+    const double ch[4][2] = {{3, f}, {f, 2 * f}, {2 * f, 4 * f}, {4 * f, 8 * f}};
+    for (int i = 0; i < 4; ++i) {
+        mac += (double)(h - 2) * (h - 2) * ch[i][0] * ch[i][1] * 9;
+        mac += (double)(h - 4) * (h - 4) * ch[i][1] * ch[i][1] * 9;
+        h = (h - 4) / 2;
+    }
+    mac += (double)(h - 2) * (h - 2) * 8 * f * 16 * f * 9;
+    mac += (double)(h - 2) * (h - 2) * 16 * f * 16 * f * 9;
+    double c = 16 * f;
+    for (int i = 0; i < 4; ++i) {
+        mac += (double)h * h * c * (c / 2) * 4;
+        h *= 2;
+        mac += (double)h * h * c * (c / 2) * 9;
+        mac += (double)(h + 2) * (h + 2) * (c / 2) * (c / 2) * 9;
+        h += 4;
+        c /= 2;
+    }
+    mac += (double)h * h * f * 3;
+    return 2 * mac;
+}
+
+// ------------------------------------------------------------------ single-layer entry points (parity tests)
+namespace {
+struct LayerPlan {
+    QpBuf in, out;
+    size_t bytes;
+};
+LayerPlan layer_plan(int kind, int B, int cin, int cout, int h, int w, char *base) {
+    LayerPlan p;
+    const int ipad = kind == ND_CONVT3 ? 2 : 0;
+    p.in.planes = 2 * nd_kblocks(cin);
+    p.in.B = B;
+    p.in.Hb = h + 2 * ipad;
+    p.in.Wb = w + 2 * ipad;
+    p.in.pad = ipad;
+    p.in.pstride = (long)B * p.in.Hb * p.in.Wb;
+    p.in.base = (float *)base;
+    size_t off = ((size_t)p.in.planes * p.in.pstride + 2 * p.in.Wb + 2 + 576) * 16;
+    off = (off + 255) & ~(size_t)255;
+    int oh, ow;
+    switch (kind) {
+        case ND_CONV3: oh = h - 2; ow = w - 2; break;
+        case ND_CONVT3: oh = h + 2; ow = w + 2; break;
+        case ND_CONVT2S2: oh = 2 * h; ow = 2 * w; break;
+        default: oh = h; ow = w; break;
+    }
+    p.out.planes = (cout + 3) / 4;
+    p.out.B = B;
+    p.out.Hb = oh;
+    p.out.Wb = ow;
+    p.out.pad = 0;
+    p.out.pstride = (long)B * oh * ow;
+    p.out.base = (float *)(base + off);
+    off += ((size_t)p.out.planes * p.out.pstride + 64) * 16;
+    p.bytes = off;
+    return p;
+}
+}  // namespace
+
+extern "C" size_t nd_layer_workspace_bytes(int kind, int batch, int cin, int cout, int h, int w, int dtype) {
+    if (dtype != ND_F32 || kind < 0 || kind > 3 || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return 0;
+    if (kind == ND_CONV3 && (h < 3 || w < 3)) return 0;
+    return layer_plan(kind, batch, cin, cout, h, w, nullptr).bytes;
+}
+
+extern "C" int nd_layer_forward(int kind, int act, float slope, int dtype, const void *packed, const float *x, int batch,
+                                int cin, int h, int w, int cout, float *y, void *ws, size_t ws_bytes, int variant,
+                                void *stream) {
+    if (dtype != ND_F32) ND_FAIL(ND_EINVAL, "nd_layer_forward: unsupported dtype %d", dtype);
+    const size_t need = nd_layer_workspace_bytes(kind, batch, cin, cout, h, w, dtype);
+    if (!need) ND_FAIL(ND_EINVAL, "nd_layer_forward: bad shape");
+    if (!ws || ws_bytes < need) ND_FAIL(ND_ENOMEM, "nd_layer_forward: workspace %zu B given, %zu B needed", ws_bytes, need);
+    if (cout % 4) ND_FAIL(ND_EINVAL, "nd_layer_forward: cout must be a multiple of 4");
+    hipStream_t s = (hipStream_t)stream;
+    LayerPlan pl = layer_plan(kind, batch, cin, cout, h, w, (char *)ws);
+    ND_HIP(hipMemsetAsync(ws, 0, need, s));
+    ND_TRY(nd_launch_nchw_to_qp(x, cin, pl.in, 0, s));
+    ConvDesc d;
+    d.kind = kind;
+    d.act = act;
+    d.slope = slope;
+    d.slope_dev = nullptr;
+    d.cin = cin;
+    d.cout = cout;
+    d.wpk = (const float *)packed;
+    d.bias = d.wpk + (size_t)nd_mtiles(kind, cout) * nd_kblocks(cin) * nd_taps(kind) * 256;
+    d.in = pl.in;
+    d.out = pl.out;
+    d.out_plane0 = 0;
+    d.variant = variant;
+    ND_TRY(nd_launch_conv_f32(d, s));
+    ND_TRY(nd_launch_qp_to_nchw(pl.out, 0, y, cout, s));
+    return ND_OK;
+}
+
+extern "C" int nd_maxpool2_forward(const float *x, int batch, int c, int h, int w, float *y, void *ws, size_t ws_bytes,
+                                   void *stream) {
+    if (batch <= 0 || c <= 0 || h < 2 || w < 2) ND_FAIL(ND_EINVAL, "nd_maxpool2_forward: bad shape");
+    QpBuf in, out;
+    in.planes = out.planes = (c + 3) / 4;
+    in.B = out.B = batch;
+    in.Hb = h; in.Wb = w; in.pad = 0; in.pstride = (long)batch * h * w;
+    out.Hb = h / 2; out.Wb = w / 2; out.pad = 0; out.pstride = (long)batch * (h / 2) * (w / 2);
+    const size_t ib = ((size_t)in.planes * in.pstride * 16 + 255) & ~(size_t)255;
+    const size_t need = ib + (size_t)out.planes * out.pstride * 16;
+    if (!ws || ws_bytes < need) ND_FAIL(ND_ENOMEM, "nd_maxpool2_forward: workspace %zu B given, %zu B needed", ws_bytes, need);
+    in.base = (float *)ws;
+    out.base = (float *)((char *)ws + ib);
+    hipStream_t s = (hipStream_t)stream;
+    ND_TRY(nd_launch_nchw_to_qp(x, c, in, 0, s));
+    ND_TRY(nd_launch_maxpool2(in, 0, in.planes, out, s));
+    ND_TRY(nd_launch_qp_to_nchw(out, 0, y, c, s));
+    return ND_OK;
+}
+
+extern "C" int nd_num_conv_variants(void) { return nd_conv_variant_count(); }
+extern "C" const char *nd_conv_variant_name(int v) { return nd_conv_variant_label(v); }

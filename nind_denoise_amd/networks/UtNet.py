@@ -1,0 +1,135 @@
+"""UtNet on MI355X: same constructor, parameter names and call contract as the reference module
+(/root/reference/src/nind_denoise/networks/UtNet.py:13-109), forward executed by libnind_hip.so.
+
+The torch layers created here are parameter CONTAINERS only (they give the module the reference's
+state-dict layout, initialisation and ``load_state_dict`` behaviour); ``forward`` never calls them.
+It repacks the weights once into MFMA fragment order, keeps the packed blob and a per-(cs, batch)
+activation workspace resident in HBM, and enqueues the whole conv stack on the current stream
+through ``nd_utnet_forward``.  There is no CPU path: a CPU tensor raises.
+"""
+import ctypes
+
+import torch
+from torch import nn
+
+from .. import _lib
+from ..synth import utnet_layer_table, utnet_prelu_keys
+
+_ACTIVATIONS = {"PReLU": nn.PReLU, "ELU": nn.ELU, "Hardswish": nn.Hardswish}
+
+
+def valid_cs(cs):
+    """The network only accepts cs = 16k + 56 (the reference raises in torch.cat otherwise)."""
+    return cs >= 104 and (cs - 56) % 16 == 0
+
+
+def nearest_valid_cs(cs):
+    k = max(0, round((cs - 56) / 16))
+    return max(104, 16 * k + 56)
+
+
+class UtNet(nn.Module):
+    def __init__(self, funit=64, activation='PReLU'):
+        super().__init__()
+        funit = int(funit)
+        if activation not in _ACTIVATIONS:
+            exit(f'UtNet: unknown activation function: {activation}')
+        self.funit, self.activation = funit, activation
+        groups = {}
+        for key, kind, cin, cout, k in utnet_layer_table(funit):
+            if kind == "conv":
+                layer = nn.Conv2d(cin, cout, k)
+            elif kind == "convT":
+                layer = nn.ConvTranspose2d(cin, cout, k)
+            else:
+                layer = nn.ConvTranspose2d(cin, cout, k, stride=2)
+            if "." in key:
+                seq, idx = key.split(".")
+                groups.setdefault(seq, {})[int(idx)] = layer
+            else:
+                groups[key] = layer
+        for key in utnet_prelu_keys():
+            seq, idx = key.split(".")
+            groups[seq][int(idx)] = _ACTIVATIONS[activation]()
+        # registration order = the reference's state-dict order (convs1..4, bottom, up1, tconvs1, up2, ...)
+        order = ["convs1", "convs2", "convs3", "convs4", "bottom"]
+        for n in range(1, 5):
+            order += [f"up{n}", f"tconvs{n}"]
+        for name in order:
+            g = groups[name]
+            self.add_module(name, nn.Sequential(*[g[i] for i in sorted(g)]) if isinstance(g, dict) else g)
+        self._packed = None       # (key, device blob)
+        self._workspaces = {}     # (device, cs, batch) -> uint8 tensor
+        self.max_cached_workspaces = 2
+
+    # ------------------------------------------------------------------ weights
+    def _weights_key(self, device):
+        return (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def packed_weights(self, device):
+        """Packed blob in HBM (re-packed when a parameter changed or moved)."""
+        key = self._weights_key(device)
+        if self._packed is not None and self._packed[0] == key:
+            return self._packed[1]
+        lib = _lib.load()
+        sd = self.state_dict()
+        names = _lib.utnet_tensor_names()
+        host = []
+        ptrs = (ctypes.c_void_p * len(names))()
+        for i, n in enumerate(names):
+            if n in sd:
+                t = sd[n].detach().to(device="cpu", dtype=torch.float32).contiguous()
+                host.append(t)
+                ptrs[i] = t.data_ptr()
+            else:
+                ptrs[i] = None  # activation without parameters (ELU / Hardswish)
+        nbytes = lib.nd_utnet_packed_bytes(self.funit, _lib.ND_F32)
+        if nbytes == 0:
+            raise ValueError(f"UtNet: funit={self.funit} is not supported by the HIP path (multiple of 8 required)")
+        blob = torch.empty(nbytes // 4, dtype=torch.float32)
+        _lib.check(lib.nd_utnet_pack_weights(self.funit, _lib.ND_F32, ptrs, len(names), blob.data_ptr(), nbytes),
+                   "nd_utnet_pack_weights")
+        dev_blob = blob.to(device)
+        self._packed = (key, dev_blob)
+        return dev_blob
+
+    def workspace(self, cs, batch, device):
+        key = (str(device), int(cs), int(batch))
+        ws = self._workspaces.get(key)
+        if ws is None:
+            lib = _lib.load()
+            nbytes = lib.nd_utnet_workspace_bytes(self.funit, cs, batch, _lib.ND_F32)
+            if nbytes == 0:
+                _lib.check(lib.nd_utnet_workspace_init(None, 0, self.funit, cs, batch, _lib.ND_F32, None), "UtNet")
+            while len(self._workspaces) >= self.max_cached_workspaces:
+                self._workspaces.pop(next(iter(self._workspaces)))
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            _lib.check(lib.nd_utnet_workspace_init(ws.data_ptr(), nbytes, self.funit, cs, batch, _lib.ND_F32,
+                                                   _lib.stream_ptr(device)), "nd_utnet_workspace_init")
+            self._workspaces[key] = ws
+        return ws
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, l):
+        if l.device.type != "cuda":
+            raise RuntimeError("nind_denoise_amd.UtNet runs on the MI355X HIP path only (no CPU fallback); "
+                               "move the module and its input to the GPU")
+        if l.dim() != 4 or l.size(1) != 3 or l.size(2) != l.size(3):
+            raise ValueError(f"UtNet expects [B,3,S,S], got {tuple(l.shape)}")
+        batch, cs = l.size(0), l.size(2)
+        if not valid_cs(cs):
+            raise ValueError(f"UtNet: tile size {cs} is not of the form 16k+56 (e.g. {nearest_valid_cs(cs)}); "
+                             "the reference network fails on it too")
+        x = l.detach().to(torch.float32).contiguous()
+        lib = _lib.load()
+        with torch.cuda.device(x.device):
+            blob = self.packed_weights(x.device)
+            ws = self.workspace(cs, batch, x.device)
+            y = torch.empty_like(x)
+            _lib.check(lib.nd_utnet_forward(self.funit, _lib.ACT[self.activation], _lib.ND_F32, blob.data_ptr(),
+                                            x.data_ptr(), y.data_ptr(), batch, cs, ws.data_ptr(), ws.numel(),
+                                            _lib.stream_ptr(x.device)), "nd_utnet_forward")
+        return y
+
+    def flops_per_tile(self, cs):
+        return _lib.load().nd_utnet_flops(self.funit, cs)

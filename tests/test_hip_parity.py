@@ -1,0 +1,327 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle and the golden fixtures.
+
+Tolerance for fp32 layers / networks: max|y_hip - y_ref| <= 1e-3 absolute per pixel (BASELINE.json north_star)
+AND, because seeded-random-weight outputs are O(0.1), max|diff| / max|y_ref| <= 1e-3.
+Tile geometry, gathered bytes and stitching of identical tile outputs: bit-exact.
+"""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from nind_denoise_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+ABS_TOL = 1e-3
+REL_TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: -m gpu tests need a real MI355X")
+    _lib.load()  # fail loudly if the HIP library is missing
+    return torch.device("cuda:0")
+
+
+def assert_close(y, ref, what=""):
+    y = y.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert y.shape == ref.shape, (what, y.shape, ref.shape)
+    assert torch.isfinite(y).all(), what
+    err = (y - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= ABS_TOL, f"{what}: max abs err {err:.3e} > {ABS_TOL}"
+    assert err <= REL_TOL * max(scale, 1e-6), f"{what}: max abs err {err:.3e} vs max|ref| {scale:.3e}"
+    return err
+
+
+# ---------------------------------------------------------------------------- single layers
+
+def layer_forward(dev, kind, x, w, b, act="none", slope=0.25, variant=-1):
+    lib = _lib.load()
+    k = _lib.KIND[kind]
+    B, cin, H, W = x.shape
+    cout = w.shape[0] if kind in ("conv3", "conv1") else w.shape[1]
+    nbytes = lib.nd_layer_packed_bytes(k, cin, cout, _lib.ND_F32)
+    packed = torch.empty(nbytes // 4, dtype=torch.float32)
+    wc, bc = w.contiguous(), b.contiguous()
+    _lib.check(lib.nd_layer_pack(k, cin, cout, _lib.ND_F32, wc.data_ptr(), bc.data_ptr(), packed.data_ptr(), nbytes))
+    packed = packed.to(dev)
+    oh, ow = {"conv3": (H - 2, W - 2), "convT3": (H + 2, W + 2), "convT2s2": (2 * H, 2 * W), "conv1": (H, W)}[kind]
+    y = torch.full((B, cout, oh, ow), float("nan"), dtype=torch.float32, device=dev)
+    wsb = lib.nd_layer_workspace_bytes(k, B, cin, cout, H, W, _lib.ND_F32)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    xd = x.to(dev).contiguous()
+    _lib.check(lib.nd_layer_forward(k, _lib.ACT[act], slope, _lib.ND_F32, packed.data_ptr(), xd.data_ptr(), B, cin, H, W,
+                                    cout, y.data_ptr(), ws.data_ptr(), wsb, variant, _lib.stream_ptr(dev)))
+    torch.cuda.synchronize()
+    return y
+
+
+def ref_layer(kind, x, w, b, act, slope):
+    if kind == "conv3" or kind == "conv1":
+        y = F.conv2d(x, w, b)
+    elif kind == "convT3":
+        y = F.conv_transpose2d(x, w, b)
+    else:
+        y = F.conv_transpose2d(x, w, b, stride=2)
+    if act == "PReLU":
+        y = F.prelu(y, torch.tensor([slope]))
+    elif act == "ELU":
+        y = F.elu(y)
+    elif act == "Hardswish":
+        y = F.hardswish(y)
+    return y
+
+
+def rnd(shape, seed, scale=1.0):
+    return (torch.rand(shape, generator=torch.Generator().manual_seed(seed)) * 2 - 1) * scale
+
+
+LAYER_CASES = [
+    # kind, B, cin, cout, H, W, act
+    ("conv3", 2, 8, 32, 20, 24, "PReLU"),
+    ("conv3", 1, 3, 64, 40, 40, "PReLU"),        # first layer: 3 channels padded to 8
+    ("conv3", 3, 64, 64, 34, 30, "PReLU"),
+    ("conv3", 1, 64, 128, 66, 66, "none"),
+    ("conv3", 2, 24, 40, 17, 19, "PReLU"),       # odd sizes, Cout not a multiple of 32
+    ("conv3", 1, 128, 256, 13, 13, "PReLU"),
+    ("convT3", 2, 16, 32, 11, 13, "PReLU"),
+    ("convT3", 1, 128, 64, 40, 36, "PReLU"),
+    ("convT3", 1, 256, 256, 11, 11, "PReLU"),
+    ("convT2s2", 2, 64, 32, 13, 13, "none"),
+    ("convT2s2", 1, 128, 64, 30, 26, "none"),
+    ("convT2s2", 1, 16, 8, 9, 7, "none"),        # 4*Cout = 32: one M tile holds all four sub-positions
+    ("conv1", 2, 64, 32, 21, 23, "none"),
+    ("conv3", 1, 16, 16, 30, 30, "ELU"),
+    ("conv3", 1, 16, 16, 30, 30, "Hardswish"),
+    ("conv3", 1, 64, 64, 270, 270, "PReLU"),     # full-width rows (Wb = 270 -> largest LDS halo image at cs=264)
+]
+
+
+@pytest.mark.parametrize("case", LAYER_CASES, ids=lambda c: "-".join(str(v) for v in c))
+def test_layer_parity(dev, case):
+    kind, B, cin, cout, H, W, act = case
+    k = {"conv3": 3, "convT3": 3, "convT2s2": 2, "conv1": 1}[kind]
+    x = rnd((B, cin, H, W), 1)
+    bound = 1.0 / np.sqrt(cin * k * k)
+    wshape = (cout, cin, k, k) if kind in ("conv3", "conv1") else (cin, cout, k, k)
+    w = rnd(wshape, 2, bound * 1.7)
+    b = rnd((cout,), 3, 0.2)
+    slope = 0.13
+    y = layer_forward(dev, kind, x, w, b, act, slope)
+    assert_close(y, ref_layer(kind, x, w, b, act, slope), str(case))
+
+
+def test_layer_asymmetric_identity(dev):
+    # exact-integer check of the fragment maps: an asymmetric integer kernel and integer inputs give integer
+    # results that must match bit for bit (a transposed tap or swapped channel pairing cannot hide)
+    cin, cout, H, W = 16, 32, 12, 14
+    x = torch.arange(cin * H * W, dtype=torch.float32).reshape(1, cin, H, W) % 17 - 8
+    w = (torch.arange(cout * cin * 9, dtype=torch.float32).reshape(cout, cin, 3, 3) % 7) - 3
+    b = torch.arange(cout, dtype=torch.float32)
+    y = layer_forward(dev, "conv3", x, w, b, "none")
+    assert torch.equal(y.cpu(), F.conv2d(x, w, b))
+    wt = (torch.arange(cout * cin * 9, dtype=torch.float32).reshape(cin, cout, 3, 3) % 5) - 2
+    y = layer_forward(dev, "convT3", x, wt, b, "none")
+    assert torch.equal(y.cpu(), F.conv_transpose2d(x, wt, b))
+    wu = (torch.arange(cout * cin * 4, dtype=torch.float32).reshape(cin, cout, 2, 2) % 5) - 2
+    y = layer_forward(dev, "convT2s2", x, wu, b, "none")
+    assert torch.equal(y.cpu(), F.conv_transpose2d(x, wu, b, stride=2))
+
+
+def test_every_conv_variant(dev):
+    lib = _lib.load()
+    x = rnd((2, 64, 36, 40), 5)
+    cases = {9: ("conv3", rnd((128, 64, 3, 3), 6, 0.07)), 1: ("conv1", rnd((128, 64, 1, 1), 7, 0.2))}
+    up_w = rnd((64, 32, 2, 2), 8, 0.1)
+    b = rnd((128,), 9, 0.1)
+    tested = 0
+    for v in range(lib.nd_num_conv_variants()):
+        name = lib.nd_conv_variant_name(v).decode()
+        if name.endswith("_uptrue"):
+            y = layer_forward(dev, "convT2s2", x, up_w, b[:32], "none", variant=v)
+            ref = F.conv_transpose2d(x, up_w, b[:32], stride=2)
+        else:
+            taps = 9 if "_t9_" in name else 1
+            kind, w = cases[taps]
+            y = layer_forward(dev, kind, x, w, b, "PReLU", 0.2, variant=v)
+            ref = F.prelu(F.conv2d(x, w, b), torch.tensor([0.2]))
+        assert_close(y, ref, name)
+        tested += 1
+    assert tested == lib.nd_num_conv_variants()
+
+
+def test_maxpool(dev):
+    lib = _lib.load()
+    x = rnd((2, 24, 26, 30), 4)
+    y = torch.empty((2, 24, 13, 15), dtype=torch.float32, device=dev)
+    ws = torch.empty(1 << 22, dtype=torch.uint8, device=dev)
+    xd = x.to(dev)
+    _lib.check(lib.nd_maxpool2_forward(xd.data_ptr(), 2, 24, 26, 30, y.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)))
+    torch.cuda.synchronize()
+    assert torch.equal(y.cpu(), F.max_pool2d(x, 2))
+
+
+# ---------------------------------------------------------------------------- tiler
+
+def _geoms():
+    with open(os.path.join(os.path.dirname(__file__), "golden", "tiler_geoms.json")) as f:
+        return json.load(f)
+
+
+def test_tile_gather_bitexact_vs_oracle_and_golden(dev):
+    import hashlib
+    from oracle import tiler as otiler
+    from nind_denoise_amd import pipeline
+    for g in _geoms():
+        frame = synth.make_frame(g["W"], g["H"], seed=g["seed"])
+        img = torch.from_numpy(frame).to(dev)
+        grid = otiler.TileGrid(g["W"], g["H"], g["cs"], g["ucs"], g["ol"])
+        ids = sorted(int(k) for k in g["tile_sha"])
+        for i in ids:
+            t = pipeline.gather_tiles(img, g["cs"], g["ucs"], g["ol"], i, 1)[0].cpu().numpy()
+            assert hashlib.sha256(t.tobytes()).hexdigest() == g["tile_sha"][str(i)], (g["W"], g["H"], i)
+        # a contiguous batch against the oracle
+        n = min(grid.size, 7)
+        t = pipeline.gather_tiles(img, g["cs"], g["ucs"], g["ol"], grid.size - n, n).cpu().numpy()
+        for k in range(n):
+            assert np.array_equal(t[k], otiler.gather_tile(frame, grid, grid.size - n + k))
+
+
+@pytest.mark.parametrize("batch", [1, 5, 64])
+def test_identity_roundtrip_bitexact(dev, batch):
+    from nind_denoise_amd import pipeline
+    for g in _geoms()[:8]:
+        if (g["cs"] - g["ucs"]) % 2:
+            continue
+        frame = synth.make_frame(g["W"], g["H"], seed=g["seed"])
+        img = torch.from_numpy(frame).to(dev)
+        out = pipeline.denoise_frame(lambda x: x, img, g["cs"], g["ucs"], g["ol"], batch=batch)
+        assert torch.equal(out, img), (g["W"], g["H"], g["cs"], g["ucs"], g["ol"])
+
+
+def test_stitch_bitexact_vs_oracle_nonidentity(dev):
+    # stitch of identical (random) tile outputs, including the cs-ucs odd quirk geometry
+    from oracle import tiler as otiler
+    from nind_denoise_amd import pipeline
+    for g in _geoms()[:8]:
+        grid = otiler.TileGrid(g["W"], g["H"], g["cs"], g["ucs"], g["ol"])
+        rng = np.random.default_rng(g["seed"])
+        tiles = rng.standard_normal((grid.size, 3, g["cs"], g["cs"]), dtype=np.float32)
+        ref = np.zeros((3, g["H"], g["W"]), dtype=np.float32)
+        for i in range(grid.size):
+            otiler.stitch_add(ref, tiles[i], grid, i)
+        canvas = torch.zeros((3, g["H"], g["W"]), dtype=torch.float32, device=dev)
+        td = torch.from_numpy(tiles).to(dev)
+        for b0 in range(0, grid.size, 5):
+            pipeline.stitch_tiles(canvas, td[b0:b0 + 5], g["cs"], g["ucs"], g["ol"], b0)
+        assert np.array_equal(canvas.cpu().numpy(), ref), (g["W"], g["H"], g["cs"], g["ucs"], g["ol"])
+
+
+def test_g24_frame_identity_full_size(dev):
+    # BASELINE config 2 geometry at full size: size-independent property (identity model reproduces the frame)
+    from nind_denoise_amd import pipeline
+    frame = synth.make_frame(6000, 4000, seed=24)
+    img = torch.from_numpy(frame).to(dev)
+    out = pipeline.denoise_frame(lambda x: x, img, 264, 200, 64, batch=128)
+    assert torch.equal(out, img)
+
+
+# ---------------------------------------------------------------------------- networks
+
+def test_utnet_f8_golden(dev, golden_dir):
+    from nind_denoise_amd.networks.UtNet import UtNet
+    d = np.load(os.path.join(golden_dir, "utnet_f8.npz"))
+    sd = {k[3:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("sd/")}
+    net = UtNet(funit=8)
+    net.load_state_dict(sd)
+    net = net.eval().to(dev)
+    for cs in (104, 120):
+        y = net(torch.from_numpy(d[f"x{cs}"]).to(dev))
+        assert_close(y, torch.from_numpy(d[f"y{cs}"]), f"utnet f8 cs{cs}")
+
+
+def test_utnet_activation_variants_golden(dev, golden_dir):
+    from nind_denoise_amd.networks.UtNet import UtNet
+    d = np.load(os.path.join(golden_dir, "utnet_act_variants.npz"))
+    for act in ("ELU", "Hardswish"):
+        net = UtNet(funit=8, activation=act)
+        net.load_state_dict(synth.make_utnet_state_dict(funit=8, seed=11, activation=act))
+        y = net.to(dev)(torch.from_numpy(d["x"]).to(dev))
+        assert_close(y, torch.from_numpy(d[f"y_{act}"]), act)
+
+
+def test_utnet_f64_cs264_golden(dev, golden_dir):
+    from nind_denoise_amd.networks.UtNet import UtNet
+    d = np.load(os.path.join(golden_dir, "utnet_f64_cs264.npz"))
+    sd = synth.make_utnet_state_dict(funit=64, seed=123)
+    assert synth.state_dict_digest(sd) == str(d["sd_digest"])
+    net = UtNet()
+    net.load_state_dict(sd)
+    net = net.eval().to(dev)
+    x = torch.from_numpy(d["x"]).to(dev)
+    err = assert_close(net(x), torch.from_numpy(d["y"]), "utnet f64 cs264")
+    # batch independence: the same tile inside a batch of 3 gives the same bits
+    xb = torch.cat([x, x.flip(3), x])
+    yb = net(xb)
+    assert torch.equal(yb[0], yb[2]) and torch.equal(yb[0], net(x)[0])
+    print(f"utnet f64 cs264 max abs err {err:.3e}")
+
+
+def test_utnet_vs_oracle_other_sizes(dev):
+    from nind_denoise_amd.networks.UtNet import UtNet
+    from oracle import networks as onet
+    sd = synth.make_utnet_state_dict(funit=16, seed=5)
+    net = UtNet(funit=16)
+    net.load_state_dict(sd)
+    net = net.to(dev)
+    for cs, B in ((104, 3), (136, 2), (184, 1)):
+        x = torch.rand(B, 3, cs, cs, generator=torch.Generator().manual_seed(cs))
+        with torch.no_grad():
+            ref = onet.utnet_forward(sd, x)
+        assert_close(net(x.to(dev)), ref, f"f16 cs{cs}")
+
+
+def test_utnet_rejects_invalid_cs_and_cpu(dev):
+    from nind_denoise_amd.networks.UtNet import UtNet
+    net = UtNet(funit=8).to(dev)
+    for cs in (128, 256, 512):
+        with pytest.raises(ValueError):
+            net(torch.zeros(1, 3, cs, cs, device=dev))
+    with pytest.raises(RuntimeError):
+        UtNet(funit=8)(torch.zeros(1, 3, 104, 104))
+
+
+def test_frame_end_to_end_vs_oracle(dev):
+    # crop -> UtNet -> stitch on a small frame: fused device loop vs the oracle loop, and fused == unfused bit for bit
+    from nind_denoise_amd import pipeline
+    from nind_denoise_amd.networks.UtNet import UtNet
+    from oracle import networks as onet
+    from oracle import tiler as otiler
+    sd = synth.make_utnet_state_dict(funit=16, seed=9)
+    net = UtNet(funit=16)
+    net.load_state_dict(sd)
+    net = net.to(dev)
+    W, H, cs, ucs, ol = 333, 290, 120, 88, 16
+    frame = synth.make_frame(W, H, seed=3)
+
+    def model_fn(x):
+        with torch.no_grad():
+            return onet.utnet_forward(sd, torch.from_numpy(x)).numpy()
+
+    ref = otiler.denoise_frame(frame, cs, ucs, ol, model_fn, batch=4)
+    img = torch.from_numpy(frame).to(dev)
+    out = pipeline.denoise_frame(net, img, cs, ucs, ol, batch=5)
+    assert_close(out, torch.from_numpy(ref), "frame e2e")
+    out2 = pipeline.denoise_frame(lambda x: net(x), img, cs, ucs, ol, batch=5)
+    assert torch.equal(out, out2), "fused gather/stitch path differs from the unfused one"
+    # a different batch size only changes how tiles are grouped, never the result
+    out3 = pipeline.denoise_frame(net, img, cs, ucs, ol, batch=3)
+    assert torch.equal(out, out3)
