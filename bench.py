@@ -29,6 +29,27 @@ if ROOT not in sys.path:
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 
 
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,14 +163,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    log(f"setup done: {total} tiles/frame, rank shard [{lo},{hi}), batch {args.batch}")
+    for i in range(args.warmup):
         step()
+        torch.cuda.synchronize()
+        log(f"warmup step {i} done")
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
+    log(f"timed {args.steps} steps in {dt:.3f} s")
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -186,6 +211,7 @@ def main():
         if not args.no_roofline and world == 1:
             b = min(args.batch, total)
             steps = conv_stack_profile(net, cs, b, dev)
+            log("conv stack profile done")
             conv_ms = sum(s["ms"] for s in steps if s["conv"])
             conv_flop = sum(s["flop"] for s in steps if s["conv"])
             achieved = conv_flop / (conv_ms * 1e-3) / 1e12
@@ -206,13 +232,11 @@ def main():
                                    tflops=round(s["flop"] / max(s["ms"], 1e-9) / 1e9, 2)) for s in steps],
             }
         if not args.no_cpu_baseline and world == 1:
-            threads = os.cpu_count() or 1
-            try:
-                threads = len(os.sched_getaffinity(0))
-            except AttributeError:
-                pass
-            n = args.cpu_sample_tiles or max(8, min(160, threads * 6))
+            threads = min(host_cores(), 64)
+            n = args.cpu_sample_tiles or max(8, min(96, threads * 4))
+            log(f"cpu baseline: {n} tiles on {threads} threads")
             cdt, tot = cpu_baseline(frame_np, sd, cs, ucs, ol, n, threads)
+            log(f"cpu baseline done in {cdt:.1f} s")
             out["cpu_baseline"] = {
                 "value": round(mp * (n / tot) / cdt, 5),
                 "unit": "MP/s",
