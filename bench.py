@@ -7,9 +7,9 @@
 A "step" is one 6000x4000 frame through the device-resident crop -> UtNet -> stitch loop (BASELINE.json configs[1],
 geometry "G24" of SURVEY.md section 8: cs=264 is the valid tile size nearest to the named 256, which the reference
 network itself rejects).  The frame is resident in HBM when the timed region starts.  With N > 1 the tile index range
-of every frame is split into N contiguous shards (one rank per GPU); inside the timed region rank 0 broadcasts the
-frame over RCCL/xGMI, every rank denoises its shard into its own canvas and the canvases are summed onto rank 0
-(each pixel receives contributions from at most two ranks, at shard seams) -> total work per step is fixed: "strong".
+of every frame is split into N contiguous shards (one rank per GPU); inside the timed region rank 0 sends every rank
+the image rows its shard reads (RCCL point-to-point over xGMI), every rank denoises its shard into its own canvas and
+rank 0 receives and adds the canvas row bands (nind_denoise_amd/dist.py) -> total work per step is fixed: "strong".
 
 One JSON line on rank 0.  `roofline` prices the conv_qp_f32 kernel family (all 22 MFMA conv launches of the stack)
 against the fp32 MFMA peak with HIP events recorded on the launch stream; `cpu_baseline` times the oracle (torch CPU
@@ -146,17 +146,22 @@ def main():
 
     frame_np = synth.make_frame(W, H, seed=24) if rank == 0 else None
     frame = torch.from_numpy(frame_np).to(dev) if rank == 0 else torch.empty((3, H, W), dtype=torch.float32, device=dev)
-    total = pipeline.tile_count(W, H, cs, ucs, ol)
-    lo, hi = (total * rank) // world, (total * (rank + 1)) // world
+    from nind_denoise_amd import dist as ndist
+    geo = ndist.Geo(W, H, cs, ucs, ol)
+    total = geo.total
+    lo, hi = geo.shard(rank, world)
     canvas = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
+
+    def compute(fr, cv, a, b):
+        pipeline.denoise_frame(net, fr, cs, ucs, ol, batch=args.batch, tile_range=(a, b), canvas=cv)
 
     def step():
         if world > 1:
-            dist.broadcast(frame, src=0)
-        canvas.zero_()
-        pipeline.denoise_frame(net, frame, cs, ucs, ol, batch=args.batch, tile_range=(lo, hi), canvas=canvas)
-        if world > 1:
-            dist.reduce(canvas, dst=0, op=dist.ReduceOp.SUM)
+            # rank 0 scatters input row bands, every rank denoises its tile shard, rank 0 gathers + adds the bands
+            ndist.denoise_frame_sharded(compute, frame, canvas, geo)
+        else:
+            canvas.zero_()
+            compute(frame, canvas, 0, total)
 
     def barrier():
         if world > 1:

@@ -1,0 +1,216 @@
+'''
+Image cropper with overlap -- MI355X native.
+
+Denoise an image: crop it into overlapping tiles with mirror padding, run every tile through the network, stitch the
+useful centres back with seamless overlap blending.  Command line, defaults, printed lines and exit behaviour follow
+/root/reference/src/nind_denoise/denoise_image.py:181-283; the crop -> infer -> stitch loop itself runs device resident
+through libnind_hip.so (pipeline.denoise_frame).
+
+egrun:
+    python -m nind_denoise_amd.denoise_image --network UtNet --model_path generator_650.pt -i in.tif -o out.tiff
+'''
+import argparse
+import math
+import os
+import sys
+import time
+
+import torch
+import yaml
+
+from . import _lib, nn_common, pipeline
+from .common.libs import np_imgops, pt_helpers, utilities
+from .networks.UtNet import nearest_valid_cs, valid_cs
+
+CS_UNET, UCS_UNET = 440, 320
+CS_UTNET, UCS_UTNET = 504, 480
+CS_UNK, UCS_UNK = 512, 448
+
+
+def make_output_fpath(input_fpath, model_fpath):
+    model_dpath = utilities.get_root(model_fpath)
+    model_fn = utilities.get_leaf(model_fpath)
+    img_fn = utilities.get_leaf(input_fpath)
+    os.makedirs(os.path.join(model_dpath, 'test', 'denoised_images'), exist_ok=True)
+    return os.path.join(model_dpath, 'test', 'denoised_images', f'{img_fn}_{model_fn}.tif')
+
+
+def autodetect_network_cs_ucs(args) -> None:
+    '''Reference rule (denoise_image.py:59-79): if EITHER cs or ucs is missing BOTH are replaced by the defaults.'''
+    if args.g_network is None:
+        print('network parameter not specified')
+        if 'unet' in args.model_path.lower():
+            args.g_network = 'UNet'
+        elif 'utnet' in args.model_path.lower():
+            args.g_network = 'UtNet'
+        else:
+            sys.exit('Could not determine network architecture from path. Please specify a "--network" type (typically UNet or UtNet)')
+        print(f'Assuming {args.g_network} from path')
+    if args.cs is None or args.ucs is None:
+        print('cs and/or ucs not set, using defaults ...')
+        if args.g_network == 'UNet':
+            args.cs, args.ucs = CS_UNET, UCS_UNET
+        elif args.g_network == 'UtNet':
+            args.cs, args.ucs = CS_UTNET, UCS_UTNET
+        else:
+            print('Warning: cs and ucs not known for this architecture; values may be sub-optimal')
+            args.cs, args.ucs = CS_UNK, UCS_UNK
+        print(f'cs={args.cs}, ucs={args.ucs}')
+
+
+class OneImageDS(torch.utils.data.Dataset):
+    '''
+    Single-image dataset which crops an image into equal pieces with overlap and adds mirror padding to the edges
+    (denoise_image.py:81-177).  The decoded frame is kept in HBM; items are gathered on the GPU by nd_tile_gather and
+    returned as the reference's triple (tile [3,cs,cs] float32, usefuldim IntTensor[4], usefulstart IntTensor[2]).
+    `inimg_fpath` may also be an in-memory float32 CHW array / tensor.
+    '''
+    def __init__(self, inimg_fpath, cs, ucs, ol, whole_image=False, pad=None, device=None):
+        if isinstance(inimg_fpath, (str, os.PathLike)):
+            inimg = torch.from_numpy(np_imgops.img_path_to_np_flt(inimg_fpath))
+        else:
+            inimg = torch.as_tensor(inimg_fpath, dtype=torch.float32)
+        self.device = torch.device(device) if device is not None else nn_common.default_device()
+        if self.device is None or self.device.type != 'cuda':
+            raise RuntimeError('OneImageDS: no GPU; nind_denoise_amd has no CPU fallback')
+        self.inimg = inimg.to(self.device).contiguous()
+        self.width, self.height = self.inimg.shape[2], self.inimg.shape[1]
+        if whole_image:
+            self.pad = pad
+            if self.pad is None or self.pad == 0:
+                self.pad = 0
+                print('OneImageDS: Warning: you should really consider (pad>0)')
+            self.whole_image = True
+            self.size = 1
+        else:
+            self.whole_image = False
+            self.cs, self.ucs, self.ol = cs, ucs, ol
+            cols, rows, self.pad = _lib.tile_grid(self.width, self.height, cs, ucs, ol)
+            self.iperhl = cols - 1
+            self.size = cols * rows
+            if self.pad == 0:
+                print('OneImageDS: Warning: you should really consider padding (cs>ucs)')
+
+    def __getitem__(self, i):
+        if i < 0 or i >= self.size:
+            raise IndexError(i)
+        if self.whole_image:
+            # one item: the whole frame with a `pad`-wide symmetric mirror border (denoise_image.py:110-128; the
+            # reference's (W+2p, H+2p) allocation is only right for square frames -- H,W are used here)
+            p = self.pad
+            ret = torch.nn.functional.pad(self.inimg[None], (p, p, p, p), mode='symmetric')[0] if p else self.inimg
+            usefuldim = (p, p, self.width + p, self.height + p)
+            usefulstart = (p, p)
+            return ret, torch.IntTensor(usefuldim), torch.IntTensor(usefulstart)
+        tile = pipeline.gather_tiles(self.inimg, self.cs, self.ucs, self.ol, i, 1)[0]
+        _, _, usefuldim, usefulstart = _lib.tile_geom(i, self.width, self.height, self.cs, self.ucs, self.ol)
+        return tile, torch.IntTensor(usefuldim), torch.IntTensor(usefulstart)
+
+    def __len__(self):
+        return self.size
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    parser.add_argument('--config', default=nn_common.COMMON_CONFIG_FPATH, help='YAML file with default values (models_dpath, ...)')
+    parser.add_argument('--cs', type=int, help='Tile size (UtNet: 16k+56, e.g. 264 or 504)')
+    parser.add_argument('--ucs', type=int, help='Useful tile size (should be <=.75*cs for U-Net, a smaller value may result in less grid artifacts but costs computation time')
+    parser.add_argument('-ol', '--overlap', default=6, type=int, help='Merge crops with this much overlap (Reduces grid artifacts, may reduce sharpness between crops, costs computation time)')
+    parser.add_argument('-i', '--input', default='in.jpg', type=str, help='Input image file')
+    parser.add_argument('-o', '--output', type=str, help='Output file with extension (default: model_dpath/test/denoised_images/fn.tif)')
+    parser.add_argument('-b', '--batch_size', type=int, default=None, help='Tiles per launch of the conv stack (results do not depend on it; default 32)')
+    parser.add_argument('--debug', action='store_true', help='Debug (display useful messages)')
+    parser.add_argument('--exif_method', default='piexif', type=str, help='How is exif data copied over? (piexif, exiftool, noexif)')
+    parser.add_argument('--g_network', '--network', '--arch', type=str, help='Generator network (typically UNet or UtNet)')
+    parser.add_argument('--model_path', help='Generator pretrained model path (.pt for dictionary), required')
+    parser.add_argument('--model_parameters', type=str, help='Model parameters with format "parameter1=value1,parameter2=value2"')
+    parser.add_argument('--max_subpixels', type=int, help='Max. number of sub-pixels, abort if exceeded.')
+    parser.add_argument('--whole_image', action='store_true', help='Ignore cs and ucs, denoise whole image')
+    parser.add_argument('--pad', type=int, help='Padding amt per side, only used for whole image (otherwise (cs-ucs)/2')
+    parser.add_argument('--models_dpath', help='Directory where all models are saved (used when a model name is provided as model_path)')
+    return parser
+
+
+def parse_args(argv=None):
+    parser = build_parser()
+    args, _ = parser.parse_known_args(argv)
+    # configargparse behaviour of the reference: values of the default YAML file fill options left unset
+    if args.config and os.path.isfile(args.config):
+        with open(args.config, 'r') as f:
+            conf = yaml.safe_load(f) or {}
+        for k, v in conf.items():
+            if hasattr(args, k) and getattr(args, k) is None:
+                setattr(args, k, v)
+    return args
+
+
+def copy_exif(args):
+    '''EXIF transplant (denoise_image.py:272-279): needs exiv2 / piexif, neither ships with this image.'''
+    if args.exif_method == 'noexif':
+        return
+    try:
+        import exiv2
+    except ImportError:
+        print(f'exif_method={args.exif_method}: exiv2 is not installed, metadata not copied (use --exif_method noexif to silence)')
+        return
+    exiv_src = exiv2.ImageFactory.open(args.input)
+    exiv_src.readMetadata()
+    exiv_dst = exiv2.ImageFactory.open(args.output)
+    exiv_dst.setExifData(exiv_src.exifData())
+    exiv_dst.writeMetadata()
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    assert args.model_path is not None
+    autodetect_network_cs_ucs(args)
+    if not torch.cuda.is_available():
+        sys.exit('denoise_image: no GPU visible; nind_denoise_amd has no CPU fallback')
+    torch.manual_seed(123)
+    device = nn_common.default_device()
+    if args.output is None:
+        args.output = make_output_fpath(args.input, args.model_path)
+    if args.model_parameters is None and 'activation' in args.model_path:
+        args.model_parameters = f"activation={args.model_path.split('activation')[-1].split('_')[1].split('_')[0]}"
+        print(f'set model_parameters to {args.model_parameters} based on model_path')
+    if args.g_network == 'UtNet' and not args.whole_image and not valid_cs(args.cs):
+        sys.exit(f'denoise_image: --cs {args.cs} is not a valid UtNet tile size (16k+56, e.g. {nearest_valid_cs(args.cs)}); '
+                 'the reference network fails on it too')
+    model = nn_common.Model.instantiate_model(network=args.g_network, model_path=args.model_path,
+                                              strparameters=args.model_parameters, keyword='generator',
+                                              device=device, models_dpath=args.models_dpath)
+    model.eval()
+    model = model.to(device)
+    ds = OneImageDS(args.input, args.cs, args.ucs, args.overlap, whole_image=args.whole_image, pad=args.pad, device=device)
+    fsheight, fswidth = ds.height, ds.width
+    batch = args.batch_size or 32
+
+    start_time = time.time()
+    if args.whole_image:
+        ybatch, usefuldims, _ = ds[0]
+        ybatch = ybatch[None]
+        if args.max_subpixels is not None and math.prod(ybatch.shape) > args.max_subpixels:
+            sys.exit(f'denoise_image.py: {ybatch.shape=}, {math.prod(ybatch.shape)=} > {args.max_subpixels=} for {args.input=}; aborting')
+        ud = usefuldims.tolist()
+        newimg = model(ybatch)[0][:, ud[1]:ud[3], ud[0]:ud[2]]
+    else:
+        if args.max_subpixels is not None and batch * 3 * args.cs * args.cs > args.max_subpixels:
+            batch = max(1, args.max_subpixels // (3 * args.cs * args.cs))
+            if 3 * args.cs * args.cs > args.max_subpixels:
+                sys.exit(f'denoise_image.py: tile of {3 * args.cs * args.cs} sub-pixels > {args.max_subpixels=} for {args.input=}; aborting')
+        nbatches = int(math.ceil(len(ds) / batch))
+
+        def progress(n, t0, cnt):
+            print(str(n) + '/' + str(nbatches))
+        newimg = pipeline.denoise_frame(model, ds.inimg, args.cs, args.ucs, args.overlap, batch=batch, progress=progress)
+    torch.cuda.synchronize()
+    pt_helpers.tensor_to_imgfile(newimg.cpu(), args.output)
+    print(f'Denoised image written to {args.output}')
+    copy_exif(args)
+    print(f'Wrote denoised image to {args.output}')
+    print('Elapsed time: ' + str(time.time() - start_time) + ' seconds')
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

@@ -1,0 +1,127 @@
+"""Multi-GPU sharding of the tile loop: one process per GPU, torch.distributed over RCCL/xGMI (backend "nccl" on ROCm).
+
+The reference has no multi-device code; tiles are independent, so the outer loop of
+denoise_image.py:240-267 is partitioned into contiguous tile-index shards, one per rank.  Per frame:
+
+  1. scatter : rank 0 sends every rank only the image rows its tiles read (shard rows + the cs-ucs halo),
+               point-to-point, all peers at once (xGMI is a full mesh: one link per peer, no ring);
+  2. compute : every rank runs the device-resident crop -> UtNet -> stitch loop on its shard into its own canvas;
+  3. gather  : every rank sends the canvas rows its tiles touched; rank 0 adds the bands in rank order.  A pixel on a
+               shard seam receives contributions from two ranks, so its fp32 sum is re-associated with respect to the
+               single-GPU tile order (<= 1 ulp); everything else is bit-identical to one GPU.
+
+The exchange logic is backend-agnostic (tests run it on gloo/CPU with world_size 2).
+"""
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+
+class Geo:
+    """Row geometry of a tile shard (pure integer, from nd_tile_grid)."""
+
+    def __init__(self, width, height, cs, ucs, ol):
+        self.W, self.H, self.cs, self.ucs, self.ol = width, height, cs, ucs, ol
+        self.cols, self.rows, self.pad = _lib.tile_grid(width, height, cs, ucs, ol)
+        self.stride = ucs - ol
+        self.total = self.cols * self.rows
+
+    def shard(self, rank, world):
+        return (self.total * rank) // world, (self.total * (rank + 1)) // world
+
+    def rows_out(self, lo, hi):
+        """canvas rows [y0, y1) written by tiles [lo, hi)"""
+        if hi <= lo:
+            return 0, 0
+        yi0, yi1 = lo // self.cols, (hi - 1) // self.cols
+        return yi0 * self.stride, min(self.H, yi1 * self.stride + self.cs - 2 * self.pad)
+
+    def rows_in(self, lo, hi):
+        """image rows [y0, y1) read by tiles [lo, hi) (mirror padding reflects inside this range)"""
+        if hi <= lo:
+            return 0, 0
+        yi0, yi1 = lo // self.cols, (hi - 1) // self.cols
+        y0 = yi0 * self.stride - self.pad
+        y1 = yi1 * self.stride - self.pad + self.cs
+        a, b = max(0, y0), min(self.H, y1)
+        if y0 < 0:
+            b = max(b, min(self.H, -y0))           # rows mirrored above the top edge
+        if y1 > self.H:
+            a = min(a, max(0, 2 * self.H - y1))    # rows mirrored below the bottom edge
+        return a, b
+
+
+def _p2p(ops, group):
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+
+def scatter_frame(frame, geo, group=None, src=0):
+    """frame: full [3,H,W] buffer on every rank; valid on `src`.  After the call each rank holds the rows it needs."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if world == 1:
+        return frame
+    if rank == src:
+        ops, keep = [], []
+        for r in range(world):
+            if r == src:
+                continue
+            a, b = geo.rows_in(*geo.shard(r, world))
+            if b > a:
+                buf = frame[:, a:b, :].contiguous()
+                keep.append(buf)
+                ops.append(dist.P2POp(dist.isend, buf, r, group))
+        _p2p(ops, group)
+    else:
+        a, b = geo.rows_in(*geo.shard(rank, world))
+        if b > a:
+            buf = torch.empty((3, b - a, geo.W), dtype=frame.dtype, device=frame.device)
+            _p2p([dist.P2POp(dist.irecv, buf, src, group)], group)
+            frame[:, a:b, :] = buf
+    return frame
+
+
+def gather_canvas(canvas, geo, group=None, dst=0):
+    """Sum every rank's canvas band onto rank `dst` (bands added in rank order)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if world == 1:
+        return canvas
+    if rank == dst:
+        ops, bufs = [], []
+        for r in range(world):
+            if r == dst:
+                continue
+            a, b = geo.rows_out(*geo.shard(r, world))
+            if b > a:
+                buf = torch.empty((3, b - a, geo.W), dtype=canvas.dtype, device=canvas.device)
+                bufs.append((a, b, buf))
+                ops.append(dist.P2POp(dist.irecv, buf, r, group))
+        _p2p(ops, group)
+        for a, b, buf in bufs:
+            canvas[:, a:b, :] += buf
+    else:
+        a, b = geo.rows_out(*geo.shard(rank, world))
+        if b > a:
+            _p2p([dist.P2POp(dist.isend, canvas[:, a:b, :].contiguous(), dst, group)], group)
+    return canvas
+
+
+def denoise_frame_sharded(compute, frame, canvas, geo, group=None, root=0):
+    """One frame across the ranks of `group`.
+
+    compute(frame, canvas, lo, hi) must add the contributions of tiles [lo, hi) to `canvas` (pipeline.denoise_frame
+    with tile_range / canvas does).  `frame` is valid on `root` on entry; the stitched result is in `canvas` on `root`.
+    """
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    scatter_frame(frame, geo, group, root)
+    lo, hi = geo.shard(rank, world)
+    a, b = geo.rows_out(lo, hi)
+    if b > a:
+        canvas[:, a:b, :].zero_()
+    if rank == root:
+        canvas.zero_()
+    compute(frame, canvas, lo, hi)
+    gather_canvas(canvas, geo, group, root)
+    return canvas

@@ -24,7 +24,7 @@ def valid_cs(cs):
 
 
 def nearest_valid_cs(cs):
-    k = max(0, round((cs - 56) / 16))
+    k = (cs - 56 + 8) // 16          # ties go up: 256 -> 264, 512 -> 520, 128 -> 136
     return max(104, 16 * k + 56)
 
 

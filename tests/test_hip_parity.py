@@ -325,3 +325,37 @@ def test_frame_end_to_end_vs_oracle(dev):
     # a different batch size only changes how tiles are grouped, never the result
     out3 = pipeline.denoise_frame(net, img, cs, ucs, ol, batch=3)
     assert torch.equal(out, out3)
+
+
+def test_cli_end_to_end(dev, tmp_path):
+    # denoise_image CLI: float TIFF in -> float TIFF out (the contract denoise.py:430-439 relies on), vs the oracle loop
+    from nind_denoise_amd import denoise_image as di
+    from nind_denoise_amd.common.libs import imgcodec, np_imgops
+    from oracle import networks as onet
+    from oracle import tiler as otiler
+    sd = synth.make_utnet_state_dict(funit=8, seed=21)
+    mdir = tmp_path / "2021-06-14T20_27_nn_train"
+    mdir.mkdir()
+    torch.save(sd, mdir / "generator_650.pt")
+    frame = synth.make_frame(310, 275, seed=8)
+    inp, outp = str(tmp_path / "x_s1.tif"), str(tmp_path / "x_s1_denoised.tiff")
+    imgcodec.write_tiff(inp, np.ascontiguousarray(frame.transpose(1, 2, 0)))
+    rc = di.main(["--network", "UtNet", "--model_path", str(mdir / "generator_650.pt"), "--model_parameters", "funit=8",
+                  "--input", inp, "--output", outp, "--cs", "120", "--ucs", "88", "-ol", "16", "--exif_method", "noexif"])
+    assert rc == 0 and os.path.isfile(outp)
+    got = np_imgops.img_path_to_np_flt(outp)
+
+    def model_fn(x):
+        with torch.no_grad():
+            return onet.utnet_forward(sd, torch.from_numpy(x)).numpy()
+
+    ref = otiler.denoise_frame(frame, 120, 88, 16, model_fn, batch=8)
+    assert_close(torch.from_numpy(got), torch.from_numpy(ref), "cli")
+    # the reference's triple from the dataset object
+    ds = di.OneImageDS(frame, 120, 88, 16, device=dev)
+    grid = otiler.TileGrid(310, 275, 120, 88, 16)
+    assert len(ds) == grid.size
+    t, ud, us = ds[len(ds) - 1]
+    assert np.array_equal(t.cpu().numpy(), otiler.gather_tile(frame, grid, grid.size - 1))
+    assert tuple(ud.tolist()) == grid.geom(grid.size - 1)[2] and tuple(us.tolist()) == grid.geom(grid.size - 1)[3]
+    assert ud.dtype == torch.int32

@@ -1,0 +1,205 @@
+"""CPU-only tests of the host side: the C-ABI library loads and exports every symbol the header declares, the
+pure-integer tile geometry entry points match the golden tables, weight packing, model-path resolution, CLI
+defaults and the image codecs.  No compute call needs a GPU here."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from nind_denoise_amd import _lib, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "nind_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(nd_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [n for n in sorted(declared) if not hasattr(lib, n)]
+    assert not missing, missing
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert _lib.load().nd_version() >= 100
+
+
+def test_tile_geometry_matches_golden_tables(golden_dir):
+    with open(os.path.join(golden_dir, "tiler_geoms.json")) as f:
+        geoms = json.load(f)
+    for g in geoms:
+        cols, rows, pad = _lib.tile_grid(g["W"], g["H"], g["cs"], g["ucs"], g["ol"])
+        assert cols * rows == g["size"] and cols == g["iperhl"] + 1 and pad == g["pad"]
+        for row in g["table"]:
+            _, _, ud, us = _lib.tile_geom(row[0], g["W"], g["H"], g["cs"], g["ucs"], g["ol"])
+            assert list(ud) + list(us) == row[1:]
+
+
+def test_tile_geometry_equals_oracle_everywhere():
+    from oracle import tiler as otiler
+    for (W, H, cs, ucs, ol) in [(6000, 4000, 264, 200, 64), (9504, 6336, 520, 456, 64), (6000, 4000, 504, 480, 6),
+                                (401, 333, 120, 87, 9), (200, 200, 264, 200, 64)]:
+        grid = otiler.TileGrid(W, H, cs, ucs, ol)
+        cols, rows, pad = _lib.tile_grid(W, H, cs, ucs, ol)
+        assert (cols, rows, pad) == (grid.cols, grid.rows, grid.pad)
+        for i in range(grid.size):
+            x0, y0, ud, us = _lib.tile_geom(i, W, H, cs, ucs, ol)
+            assert (x0, y0, ud, us) == grid.geom(i)
+    assert _lib.tile_grid(6000, 4000, 264, 200, 64)[:2] == (44, 29)       # G24: 1276 tiles
+    assert _lib.tile_grid(9504, 6336, 520, 456, 64)[:2] == (25, 16)       # G61: 400 tiles
+    assert _lib.tile_grid(6000, 4000, 504, 480, 6)[:2] == (13, 9)         # G24d: 117 tiles
+
+
+def test_tile_geometry_errors():
+    with pytest.raises(ValueError):
+        _lib.tile_grid(100, 100, 264, 200, 64)     # frame smaller than ucs: undefined in the reference
+    with pytest.raises(ValueError):
+        _lib.tile_grid(500, 500, 264, 200, 200)    # ucs must exceed the overlap
+    with pytest.raises(ValueError):
+        _lib.tile_geom(99, 500, 700, 264, 200, 64)
+
+
+def _ref_pack(kind, cin, cout, w):
+    taps = 9 if kind in ("conv3", "convT3") else 1
+    M = 4 * cout if kind == "convT2s2" else cout
+    MT, KB = (M + 127) // 128 * 4, (cin + 7) // 8
+    out = np.zeros((MT, KB, taps, 64, 4), dtype=np.float32)
+    for mt in range(MT):
+        for lane in range(64):
+            i, h = lane & 31, lane >> 5
+            m = 32 * mt + i
+            if m >= M:
+                continue
+            for kb in range(KB):
+                for s in range(4):
+                    ci = 8 * kb + 4 * h + s
+                    if ci >= cin:
+                        continue
+                    for t in range(taps):
+                        if kind == "conv3":
+                            v = w[m, ci, t // 3, t % 3]
+                        elif kind == "convT3":
+                            v = w[ci, m, 2 - t // 3, 2 - t % 3]
+                        elif kind == "convT2s2":
+                            ab, co = divmod(m, cout)
+                            v = w[ci, co, ab >> 1, ab & 1]
+                        else:
+                            v = w[m, ci, 0, 0]
+                        out[mt, kb, t, lane, s] = v
+    return out.reshape(-1)
+
+
+@pytest.mark.parametrize("kind,cin,cout", [("conv3", 3, 8), ("conv3", 16, 40), ("convT3", 24, 16), ("convT2s2", 16, 8),
+                                           ("conv1", 8, 12)])
+def test_weight_packing(kind, cin, cout):
+    lib = _lib.load()
+    k = {"conv3": 3, "convT3": 3, "convT2s2": 2, "conv1": 1}[kind]
+    shape = (cout, cin, k, k) if kind in ("conv3", "conv1") else (cin, cout, k, k)
+    w = torch.randn(shape, generator=torch.Generator().manual_seed(1))
+    b = torch.randn(cout, generator=torch.Generator().manual_seed(2))
+    nbytes = lib.nd_layer_packed_bytes(_lib.KIND[kind], cin, cout, _lib.ND_F32)
+    packed = torch.empty(nbytes // 4)
+    _lib.check(lib.nd_layer_pack(_lib.KIND[kind], cin, cout, _lib.ND_F32, w.data_ptr(), b.data_ptr(), packed.data_ptr(), nbytes))
+    ref = _ref_pack(kind, cin, cout, w.numpy())
+    assert np.array_equal(packed.numpy()[:ref.size], ref)
+    bias = packed.numpy()[ref.size:]
+    M = 4 * cout if kind == "convT2s2" else cout
+    assert np.array_equal(bias[:M], np.tile(b.numpy(), 4 if kind == "convT2s2" else 1))
+    assert not bias[M:].any()
+    with pytest.raises(MemoryError):
+        _lib.check(lib.nd_layer_pack(_lib.KIND[kind], cin, cout, _lib.ND_F32, w.data_ptr(), b.data_ptr(), packed.data_ptr(), 16))
+
+
+def test_utnet_module_has_reference_state_dict_layout(golden_dir):
+    from nind_denoise_amd.networks.UtNet import UtNet
+    net = UtNet()
+    sd = net.state_dict()
+    assert list(sd.keys()) == _lib.utnet_tensor_names()
+    assert len(sd) == 64 and sum(p.numel() for p in net.parameters()) == 31_031_893
+    assert tuple(sd["bottom.2.weight"].shape) == (1024, 1024, 3, 3) and tuple(sd["up1.weight"].shape) == (1024, 512, 2, 2)
+    assert tuple(sd["tconvs4.4.weight"].shape) == (3, 64, 1, 1) and tuple(sd["convs1.1.weight"].shape) == (1,)
+    # the fixture state-dict produced for the REFERENCE module loads strictly
+    d = np.load(os.path.join(golden_dir, "utnet_f8.npz"))
+    UtNet(funit=8).load_state_dict({k[3:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("sd/")}, strict=True)
+    UtNet(funit=8, activation="ELU").load_state_dict(synth.make_utnet_state_dict(8, 1, "ELU"), strict=True)
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 3, 104, 104))  # CPU tensor: no fallback
+
+
+def test_utnet_pack_whole_net_and_sizes():
+    lib = _lib.load()
+    assert lib.nd_utnet_flops(64, 264) == 84_830_297_600.0
+    assert lib.nd_utnet_flops(64, 256) == 0.0
+    assert lib.nd_utnet_workspace_bytes(64, 256, 1, 0) == 0
+    assert lib.nd_utnet_workspace_bytes(64, 264, 4, 0) > 4 * 150e6
+    from nind_denoise_amd.networks.UtNet import UtNet, nearest_valid_cs, valid_cs
+    assert [nearest_valid_cs(c) for c in (128, 256, 512, 50)] == [136, 264, 520, 104]
+    assert valid_cs(264) and valid_cs(504) and not valid_cs(256)
+
+
+def test_model_path_resolution(tmp_path):
+    from nind_denoise_amd.nn_common import Model
+    d = tmp_path / "2021-run"
+    d.mkdir()
+    for e in (3, 12, 7):
+        (d / f"generator_{e}.pt").write_bytes(b"")
+    (d / "discriminator_99.pt").write_bytes(b"")
+    assert Model.complete_path(str(d), None, keyword="generator").endswith("generator_12.pt")
+    (d / "trainres.json").write_text(json.dumps({"best_epoch": {"validation_loss": 7}}))
+    assert Model.complete_path(str(d), None, keyword="generator").endswith("generator_7.pt")
+    assert Model.complete_path("2021-run", str(tmp_path), keyword="generator").endswith("generator_7.pt")
+    f = d / "generator_3.pt"
+    assert Model.complete_path(str(f), None) == str(f)
+    with pytest.raises(FileNotFoundError):
+        Model.complete_path(str(tmp_path / "nope"), str(tmp_path))
+    # state-dict round trip through instantiate_model (stays on CPU: no forward)
+    from nind_denoise_amd.networks.UtNet import UtNet
+    sd = synth.make_utnet_state_dict(8, 3)
+    torch.save(sd, d / "generator_7.pt")
+    m = Model.instantiate_model(model_path=str(d), network="UtNet", device="cpu", strparameters="funit=8", keyword="generator")
+    assert isinstance(m, UtNet) and torch.equal(m.state_dict()["up2.bias"], sd["up2.bias"])
+
+
+def test_cli_defaults_and_autodetect():
+    from nind_denoise_amd import denoise_image as di
+    a = di.parse_args(["--model_path", "m/x_utnet_y/generator_650.pt"])
+    assert (a.overlap, a.input, a.exif_method, a.batch_size) == (6, "in.jpg", "piexif", None)
+    di.autodetect_network_cs_ucs(a)
+    assert (a.g_network, a.cs, a.ucs) == ("UtNet", 504, 480)
+    a = di.parse_args(["--network", "UNet", "--model_path", "g.pt", "--cs", "300"])   # ucs missing -> both replaced
+    di.autodetect_network_cs_ucs(a)
+    assert (a.cs, a.ucs) == (440, 320)
+    a = di.parse_args(["--arch", "UtNet", "--model_path", "g.pt", "--cs", "264", "--ucs", "200", "-ol", "64", "-b", "8"])
+    di.autodetect_network_cs_ucs(a)
+    assert (a.g_network, a.cs, a.ucs, a.overlap, a.batch_size) == ("UtNet", 264, 200, 64, 8)
+    with pytest.raises(SystemExit):
+        di.autodetect_network_cs_ucs(di.parse_args(["--model_path", "nothing_recognisable.pt"]))
+
+
+def test_image_codecs_roundtrip(tmp_path):
+    from PIL import Image
+    from nind_denoise_amd.common.libs import imgcodec, np_imgops, pt_helpers
+    rng = np.random.default_rng(0)
+    t = torch.from_numpy(rng.random((3, 41, 57), dtype=np.float32) * 1.2 - 0.1)   # values outside [0,1]
+    p32 = str(tmp_path / "o.tiff")
+    pt_helpers.tensor_to_imgfile(t, p32)                        # 'tiff' -> float32, NOT clipped
+    assert np.array_equal(np_imgops.img_path_to_np_flt(p32), t.numpy())
+    for ext in (".tif", ".png"):                                # 16-bit: round(clip(x)*65535)
+        p16 = str(tmp_path / ("o" + ext))
+        pt_helpers.tensor_to_imgfile(t, p16)
+        want = (t.clip(0, 1) * 65535).round().numpy().astype(np.uint16).astype(np.float32) / 65535
+        assert np.array_equal(np_imgops.img_path_to_np_flt(p16), want)
+    pj = str(tmp_path / "o.jpg")
+    pt_helpers.tensor_to_imgfile(t, pj)
+    assert np_imgops.img_path_to_np_flt(pj).shape == (3, 41, 57)
+    x8 = (rng.random((33, 47, 3)) * 255).astype(np.uint8)
+    for comp in (None, "tiff_lzw", "tiff_adobe_deflate", "packbits"):
+        Image.fromarray(x8).save(str(tmp_path / "p.tif"), compression=comp)
+        assert np.array_equal(imgcodec.read_tiff(str(tmp_path / "p.tif")), x8), comp
+    Image.fromarray(x8).save(str(tmp_path / "p.png"))           # PIL picks per-row filters, Paeth included
+    assert np.array_equal(imgcodec.read_png(str(tmp_path / "p.png")), x8)
+    with pytest.raises(FileNotFoundError):
+        np_imgops.img_path_to_np_flt(str(tmp_path / "missing.tif"))
