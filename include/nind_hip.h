@@ -130,6 +130,12 @@ int nd_layer_forward(int kind, int act, float slope, int dtype, const void *pack
 int nd_maxpool2_forward(const float *x_nchw, int batch, int c, int h, int w, float *y_nchw,
                         void *workspace, size_t workspace_bytes, void *stream);
 
+/* Kernel micro-benchmark: `iters` launches of one conv layer (variant -1 = automatic choice) on pseudo-random
+ * quad-planar data carved from `workspace` (nd_layer_workspace_bytes + nd_layer_packed_bytes + 256 B); mean launch
+ * duration from HIP events on `stream`.  Synchronises the stream. */
+int nd_conv_bench(int kind, int batch, int cin, int cout, int h, int w, int variant, int iters,
+                  void *workspace, size_t workspace_bytes, void *stream, float *mean_ms);
+
 /* Name and average duration bookkeeping for bench.py: number of conv-kernel variants compiled in. */
 int nd_num_conv_variants(void);
 const char *nd_conv_variant_name(int variant);

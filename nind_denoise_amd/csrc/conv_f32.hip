@@ -19,13 +19,23 @@
 //   channels 8g+4h.. of pixel j  => one float4 store per (g) lands in the quad-planar output, 512 B contiguous per
 //   half wave.
 //
-// Pipeline: 2 LDS stages filled by LDS-DMA (global_load_lds_dwordx4); per K chunk ONE workgroup barrier:
-//   wait vmcnt(0) -> s_barrier -> issue the DMA of chunk c+1 into the other stage -> MFMAs of chunk c.
+// Schedule: PERSISTENT workgroups (one per CU) walk a stream of (output tile, K chunk) steps.  LDS holds NSTAGE stage
+// images (weights + activation halo image of one K chunk) filled by LDS-DMA (global_load_lds_dwordx4):
+//   NSTAGE = 3: the DMA of step s+2 is issued at the top of step s; one barrier per step proves that step s+1 has landed
+//               for every wave, so the first fragments of step s+1 are read BEFORE the next barrier and the matrix pipe
+//               never drains at a step boundary -- nor at a tile boundary: the next tile's first chunks are already
+//               in flight while the epilogue stores of the finished tile are issued.
+//   NSTAGE = 2: (rows too wide for three stage images) DMA of step s+1 issued at the top of step s, fragments read after
+//               the barrier.
+// Workgroup ids are remapped so that the 32 workgroups sharing an XCD (and its L2) walk adjacent tiles.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "nd_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct ConvParams {
@@ -46,12 +56,22 @@ struct ConvParams {
     int act;
     float slope;
     const float *slope_dev;
+    int n_tiles_n;       // N tiles (pixels / NBLK, rounded up)
+    int n_tiles_m;       // M tiles (rows / MBLK, rounded up)
+    int ablate;          // diagnostics only (NIND_ABLATE): 1 no DMA, 2 no barrier, 4 no stores, 8 no LDS fragment reads
 };
 
 __device__ __forceinline__ void glds16(const void *g, void *l) {
     // 64 lanes x 16 B: per-lane global source, LDS destination = wave-uniform base + lane*16
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                      (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+}
+
+// 8 consecutive floats at a wave-uniform address through the scalar cache (lgkmcnt, not vmcnt)
+__device__ __forceinline__ f32x8 sload8(const float *p) {
+    f32x8 v;
+    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
 }
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
@@ -64,21 +84,24 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 }
 
 // MR x NR : 32x32 MFMA tiles per wave;  WM x WN : waves per workgroup;  TAPS in {9,1};  KBC : 8-channel blocks per chunk
-template <int MR, int NR, int WM, int WN, int TAPS, int KBC, bool UP>
+template <int MR, int NR, int WM, int WN, int TAPS, int KBC, bool UP, int NSTAGE>
 __global__ __launch_bounds__(64 * WM * WN) void conv_qp_f32(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = WM * WN;
     constexpr int MTB = MR * WM;                    // 32-row tiles per workgroup
-    constexpr int NBLK = 32 * NR * WN;              // pixels per workgroup
+    constexpr int NBLK = 32 * NR * WN;              // pixels per workgroup tile
     constexpr int WBYTES = MTB * KBC * TAPS * 1024; // weight bytes per stage
+    constexpr int STEPS = KBC * TAPS;               // fragment sub-steps per K chunk
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int j = lane & 31, h = lane >> 5;
 
-    const int mb = blockIdx.y;
-    const long n0 = (long)blockIdx.x * NBLK;
+    // XCD-aware id: hardware deals workgroups round-robin over the 8 XCDs; give each XCD a contiguous id range
+    const int nwg = gridDim.x;
+    const int bid = blockIdx.x;
+    const int vb = (nwg % 8 == 0) ? (bid % 8) * (nwg / 8) + bid / 8 : bid;
 
     const int halo = (TAPS == 9) ? 2 * p.Wb + 2 : 0;
     const int G = (NBLK + halo + 63) >> 6;   // 64-pixel DMA pieces per channel-quad plane
@@ -89,91 +112,103 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_qp_f32(ConvParams p) {
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) toff[t] = (TAPS == 9) ? ((t / 3) * p.Wb + (t % 3)) * 16 : 0;
 
-    const float *wsrc = p.wpk + (size_t)mb * MTB * p.KB * TAPS * 256 + lane * 4;
-    const f32x4 *asrc = p.in + n0 + lane;
+    const int nchunks = p.KB / KBC;
+    const int ntiles = p.n_tiles_n * p.n_tiles_m;
+    const int my_tiles = vb < ntiles ? (ntiles - vb + nwg - 1) / nwg : 0;
+    const int nsteps = my_tiles * nchunks;
+    if (nsteps == 0) return;
 
-    auto fill = [&](int c, int s) {
-        char *sb = smem + s * stageB;
-        // weights: for each of the workgroup's m-tiles, KBC*TAPS consecutive 1 KiB pieces
+    // ---- DMA cursor: walks the same (tile, chunk) stream as the compute loop, NSTAGE-1 steps ahead
+    int f_id = vb, f_c = 0, f_stage = 0, issued = 0;
+    const float *f_w;
+    const f32x4 *f_a;
+    auto set_fill_tile = [&](int id) {
+        const int nb = id / p.n_tiles_m, mb = id - nb * p.n_tiles_m;   // M tiles of one N tile run back to back
+        f_w = p.wpk + (size_t)mb * MTB * p.KB * TAPS * 256 + lane * 4;
+        f_a = p.in + (long)nb * NBLK + lane;
+    };
+    set_fill_tile(f_id);
+    // With two waves per SIMD (NW == 8) only waves 0..3 -- one per SIMD -- issue the DMA: their SIMD partners (waves
+    // 4..7) go straight to their MFMAs, so the matrix pipe is fed while the DMA instructions are being issued.
+    constexpr int NFILL = NW > 4 ? 4 : NW;
+    auto fill_next = [&]() {
+        if (issued >= nsteps) return;
+        char *sb = smem + f_stage * stageB;
+        if (wave < NFILL && !(p.ablate & 1)) {
 #pragma unroll
-        for (int mt = 0; mt < MTB; ++mt) {
-            const float *src = wsrc + ((size_t)mt * p.KB + (size_t)c * KBC) * TAPS * 256;
-            char *dst = sb + mt * KBC * TAPS * 1024;
-            for (int q = wave; q < KBC * TAPS; q += NW) glds16(src + q * 256, dst + q * 1024);
-        }
-        // activations: 2*KBC channel-quad planes, G pieces each
+            for (int mt = 0; mt < MTB; ++mt) {
+                const float *src = f_w + ((size_t)mt * p.KB + (size_t)f_c * KBC) * TAPS * 256;
+                char *dst = sb + mt * KBC * TAPS * 1024;
+                for (int q = wave; q < KBC * TAPS; q += NFILL) glds16(src + q * 256, dst + q * 1024);
+            }
 #pragma unroll
-        for (int pl = 0; pl < 2 * KBC; ++pl) {
-            const f32x4 *src = asrc + (size_t)(c * 2 * KBC + pl) * p.in_plane;
-            char *dst = sb + WBYTES + pl * planeB;
-            for (int g = wave; g < G; g += NW) glds16(src + g * 64, dst + g * 1024);
+            for (int pl = 0; pl < 2 * KBC; ++pl) {
+                const f32x4 *src = f_a + (size_t)(f_c * 2 * KBC + pl) * p.in_plane;
+                char *dst = sb + WBYTES + pl * planeB;
+                for (int g = wave; g < G; g += NFILL) glds16(src + g * 64, dst + g * 1024);
+            }
         }
+        ++issued;
+        f_stage = (f_stage + 1 == NSTAGE) ? 0 : f_stage + 1;
+        if (++f_c == nchunks) {
+            f_c = 0;
+            f_id += nwg;
+            if (f_id < ntiles) set_fill_tile(f_id);
+        }
+    };
+
+    // ---- fragments
+    const int aOff = (wm * MR) * KBC * TAPS * 1024 + lane * 16;
+    const int bOff = WBYTES + h * planeB + (wn * NR * 32 + j) * 16;
+    f32x4 a[2][MR] = {}, b[2][NR] = {};
+    auto load_frags = [&](int buf, const char *sb, int step) {
+        if (p.ablate & 8) return;
+        const int kbl = step / TAPS, t = step % TAPS;
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+            a[buf][mr] = *(const f32x4 *)(sb + aOff + ((mr * KBC + kbl) * TAPS + t) * 1024);
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr)
+            b[buf][nr] = *(const f32x4 *)(sb + bOff + kbl * 2 * planeB + toff[t] + nr * 512);
     };
 
     f32x16 acc[MR][NR];
 #pragma unroll
-    for (int a = 0; a < MR; ++a)
+    for (int x = 0; x < MR; ++x)
 #pragma unroll
-        for (int b = 0; b < NR; ++b)
+        for (int y = 0; y < NR; ++y)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
 
-    const int nchunks = p.KB / KBC;
-    fill(0, 0);
-    for (int c = 0; c < nchunks; ++c) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (c + 1 < nchunks) fill(c + 1, (c + 1) & 1);
-        const char *sb = smem + (c & 1) * stageB;
-        const char *aB = sb + (wm * MR) * KBC * TAPS * 1024 + lane * 16;
-        const char *bB = sb + WBYTES + h * planeB + (wn * NR * 32 + j) * 16;
-        // fragments of step i+1 are fetched before the MFMAs of step i (one wave per SIMD has nobody else to hide
-        // the LDS latency); every index below is a compile-time constant after unrolling
-        constexpr int STEPS = KBC * TAPS;
-        f32x4 a[2][MR], b[2][NR];
-        auto load_frags = [&](int buf, int step) {
-            const int kbl = step / TAPS, t = step % TAPS;
-#pragma unroll
-            for (int mr = 0; mr < MR; ++mr)
-                a[buf][mr] = *(const f32x4 *)(aB + ((mr * KBC + kbl) * TAPS + t) * 1024);
-#pragma unroll
-            for (int nr = 0; nr < NR; ++nr)
-                b[buf][nr] = *(const f32x4 *)(bB + kbl * 2 * planeB + toff[t] + nr * 512);
-        };
-        load_frags(0, 0);
-#pragma unroll
-        for (int st = 0; st < STEPS; ++st) {
-            if (st + 1 < STEPS) load_frags((st + 1) & 1, st + 1);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-                    for (int nr = 0; nr < NR; ++nr)
-                        acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st & 1][mr][s], b[st & 1][nr][s], acc[mr][nr], 0, 0, 0);
-        }
-    }
-
-    // ---- epilogue: bias + activation, float4 stores into the (bordered, possibly concatenated) destination
     const float slope = p.act == ND_ACT_NONE ? 1.f : (p.slope_dev ? *p.slope_dev : p.slope);
-    auto epilogue = [&](auto generic_act) {
+
+    // ---- epilogue of one finished tile: bias + activation, float4 stores into the (bordered, concatenated) destination
+    auto epilogue = [&](int id, auto generic_act) {
+        const int nb = id / p.n_tiles_m, mb = id - nb * p.n_tiles_m;
+        const long n0 = (long)nb * NBLK;
 #pragma unroll
         for (int nr = 0; nr < NR; ++nr) {
             const long pix = n0 + (wn * NR + nr) * 32 + j;
-            const int b = (int)(pix / p.P);
-            const int r = (int)(pix - (long)b * p.P);
+            const int bi = (int)(pix / p.P);
+            const int r = (int)(pix - (long)bi * p.P);
             const int y = r / p.Wb;
             const int x = r - y * p.Wb;
             const bool valid = pix < p.NP && y < p.Hv && x < p.Wv;
-            const long pbase = UP ? (long)b * p.Po + (long)(2 * y + p.opad) * p.Wo + (2 * x + p.opad)
-                                  : (long)b * p.Po + (long)(y + p.opad) * p.Wo + (x + p.opad);
+            const long pbase = UP ? (long)bi * p.Po + (long)(2 * y + p.opad) * p.Wo + (2 * x + p.opad)
+                                  : (long)bi * p.Po + (long)(y + p.opad) * p.Wo + (x + p.opad);
 #pragma unroll
             for (int mr = 0; mr < MR; ++mr) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int m4 = ((mb * MTB + wm * MR + mr) * 32) + 8 * g + 4 * h;
+                    // bias through the scalar cache (a vector load here would make the compiler wait vmcnt(0), i.e. for
+                    // the LDS-DMA of the next steps that is in flight during the epilogue)
+                    const int m8 = ((mb * MTB + wm * MR + mr) * 32) + 8 * g;   // wave-uniform
+                    const f32x8 b8 = sload8(p.bias + m8);
+                    const int m4 = m8 + 4 * h;
                     if (valid && m4 < p.M) {
-                        const f32x4 bv = *(const f32x4 *)(p.bias + m4);
+                        f32x4 bv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) bv[e] = h ? b8[4 + e] : b8[e];
                         f32x4 v;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -191,64 +226,122 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_qp_f32(ConvParams p) {
                         } else {
                             off = (long)(p.out_plane0 + (m4 >> 2)) * p.out_plane + pbase;
                         }
-                        p.out[off] = v;
+                        if (!(p.ablate & 4)) p.out[off] = v;
                     }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[mr][nr][4 * g + e] = 0.f;
                 }
             }
         }
     };
-    if (p.act <= ND_ACT_PRELU)
-        epilogue(std::false_type{});
-    else
-        epilogue(std::true_type{});
+
+    // ---- prologue
+#pragma unroll
+    for (int i = 0; i < NSTAGE - 1; ++i) fill_next();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (NSTAGE == 3) load_frags(0, smem, 0);
+
+    int c_id = vb, c_c = 0, c_stage = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        // my share of the youngest outstanding DMA was issued one whole step ago
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(p.ablate & 2)) __builtin_amdgcn_s_barrier();
+        fill_next();
+        const char *sb = smem + c_stage * stageB;
+        const int n_stage = (c_stage + 1 == NSTAGE) ? 0 : c_stage + 1;
+        if (NSTAGE == 2) load_frags(0, sb, 0);
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+            if (st + 1 < STEPS)
+                load_frags((st + 1) & 1, sb, st + 1);
+            else if (NSTAGE == 3 && s + 1 < nsteps)
+                load_frags((st + 1) & 1, smem + n_stage * stageB, 0);   // next step's first fragments, before its barrier
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                    for (int nr = 0; nr < NR; ++nr)
+                        acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st & 1][mr][q], b[st & 1][nr][q], acc[mr][nr], 0, 0, 0);
+        }
+        if (NSTAGE == 3 && (STEPS & 1)) {
+            // an odd number of sub-steps leaves the prefetched fragments in buffer 1: the next step starts from buffer 0
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr) a[0][mr] = a[1][mr];
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) b[0][nr] = b[1][nr];
+        }
+        c_stage = n_stage;
+        if (++c_c == nchunks) {
+            if (p.act <= ND_ACT_PRELU)
+                epilogue(c_id, std::false_type{});
+            else
+                epilogue(c_id, std::true_type{});
+            c_c = 0;
+            c_id += nwg;
+        }
+    }
 }
 
 // ------------------------------------------------------------------ variants and dispatch
 struct Variant {
     const char *name;
-    int mblk, nblk, threads, taps, kbc;
+    int mblk, nblk, threads, taps, kbc, nstage;
     bool up;
     void (*fn)(ConvParams);
 };
 
-#define ND_VARIANT(MR, NR, WM, WN, TAPS, KBC, UP)                                                            \
-    {                                                                                                        \
-        "f32_m" #MR "x" #WM "_n" #NR "x" #WN "_t" #TAPS "_k" #KBC "_up" #UP, 32 * MR * WM, 32 * NR * WN, 64 * WM * WN, TAPS, KBC, UP, \
-            conv_qp_f32<MR, NR, WM, WN, TAPS, KBC, UP>                                                       \
+#define ND_VARIANT(MR, NR, WM, WN, TAPS, KBC, UP, NS)                                                               \
+    {                                                                                                               \
+        "f32_m" #MR "x" #WM "_n" #NR "x" #WN "_t" #TAPS "_k" #KBC "_up" #UP "_s" #NS, 32 * MR * WM, 32 * NR * WN,   \
+            64 * WM * WN, TAPS, KBC, NS, UP, conv_qp_f32<MR, NR, WM, WN, TAPS, KBC, UP, NS>                         \
     }
 
 static const Variant g_variants[] = {
-    ND_VARIANT(2, 2, 1, 4, 9, 1, false),  // 0: M64  x N256, 4 waves
-    ND_VARIANT(2, 2, 2, 2, 9, 1, false),  // 1: M128 x N128, 4 waves
-    ND_VARIANT(2, 2, 2, 4, 9, 1, false),  // 2: M128 x N256, 8 waves
-    ND_VARIANT(2, 2, 1, 8, 9, 1, false),  // 3: M64  x N512, 8 waves
-    ND_VARIANT(1, 2, 1, 4, 9, 1, false),  // 4: M32  x N256, 4 waves (narrow nets / tests)
-    ND_VARIANT(2, 2, 1, 4, 1, 2, false),  // 5: 1x1, M64 x N256
-    ND_VARIANT(2, 2, 2, 2, 1, 2, false),  // 6: 1x1, M128 x N128
-    ND_VARIANT(2, 2, 1, 4, 1, 2, true),   // 7: up (2x2 s2), M64 x N256
-    ND_VARIANT(2, 2, 2, 2, 1, 2, true),   // 8: up, M128 x N128
-    ND_VARIANT(2, 2, 2, 4, 1, 2, true),   // 9: up, M128 x N256, 8 waves
-    ND_VARIANT(2, 2, 1, 4, 1, 1, false),  // 10: 1x1, KBC=1 (Cin == 8)
-    ND_VARIANT(2, 2, 1, 4, 1, 1, true),   // 11: up, KBC=1
+    ND_VARIANT(2, 2, 1, 8, 9, 1, false, 3),  // 0: M64  x N512, 8 waves, 3 stages  (default 3x3)
+    ND_VARIANT(2, 2, 1, 8, 9, 1, false, 2),  // 1: M64  x N512, 8 waves, 2 stages  (wide rows: cs >= ~400)
+    ND_VARIANT(2, 2, 1, 4, 9, 1, false, 2),  // 2: M64  x N256, 4 waves, 2 stages  (widest rows)
+    ND_VARIANT(2, 2, 2, 4, 9, 1, false, 3),  // 3: M128 x N256, 8 waves, 3 stages
+    ND_VARIANT(1, 2, 1, 8, 9, 1, false, 3),  // 4: M32  x N512, 8 waves (narrow nets / tests)
+    ND_VARIANT(2, 2, 1, 4, 9, 1, false, 3),  // 5: M64  x N256, 4 waves, 3 stages
+    ND_VARIANT(2, 2, 1, 8, 1, 2, false, 3),  // 6: 1x1, M64 x N512
+    ND_VARIANT(2, 2, 1, 8, 1, 1, false, 3),  // 7: 1x1, K chunk of 8 channels (Cin == 8 mod 16)
+    ND_VARIANT(2, 2, 1, 8, 1, 2, true, 3),   // 8: up (2x2 s2), M64 x N512
+    ND_VARIANT(2, 2, 2, 4, 1, 2, true, 3),   // 9: up, M128 x N256
+    ND_VARIANT(2, 2, 1, 8, 1, 1, true, 3),   // 10: up, K chunk of 8 channels
+    ND_VARIANT(2, 2, 2, 2, 1, 2, true, 2),   // 11: up, M128 x N128, 4 waves, 2 stages
 };
 static const int g_nvariants = (int)(sizeof(g_variants) / sizeof(g_variants[0]));
 
 int nd_conv_variant_count() { return g_nvariants; }
 const char *nd_conv_variant_label(int v) { return (v >= 0 && v < g_nvariants) ? g_variants[v].name : ""; }
 
-static int pick_variant(const ConvDesc &d, int M, long NP) {
+static size_t variant_lds(const Variant &V, int Wb) {
+    const int halo = V.taps == 9 ? 2 * Wb + 2 : 0;
+    const int G = (V.nblk + halo + 63) / 64;
+    return (size_t)V.nstage * ((size_t)(V.mblk / 32) * V.kbc * V.taps * 1024 + (size_t)2 * V.kbc * G * 1024);
+}
+
+static const size_t kMaxLds = 160 * 1024;
+
+static int pick_variant(const ConvDesc &d, int M) {
     const int taps = nd_taps(d.kind);
     const bool up = d.kind == ND_CONVT2S2;
     const int KB = nd_kblocks(d.cin);
     if (taps == 9) {
-        if (M <= 32) return 4;
-        if (M <= 64) return 0;
-        return 1;
+        const int first = M <= 32 ? 4 : 0;
+        const int order[] = {first, 0, 1, 2};
+        for (int v : order)
+            if (variant_lds(g_variants[v], d.in.Wb) <= kMaxLds) return v;
+        return 2;
     }
-    if (KB % 2) return up ? 11 : 10;
-    if (up) return M <= 64 ? 7 : 8;
-    return M <= 64 ? 5 : 6;
+    if (KB % 2) return up ? 10 : 7;
+    return up ? 8 : 6;
 }
+
+static int g_num_cus = 0;
+static int g_lds_set[64] = {0};
 
 int nd_launch_conv_f32(const ConvDesc &d, hipStream_t stream) {
     const int taps = nd_taps(d.kind);
@@ -260,7 +353,7 @@ int nd_launch_conv_f32(const ConvDesc &d, hipStream_t stream) {
     const long NP = d.in.used();
     if (NP >= (1L << 31)) ND_FAIL(ND_EINVAL, "conv: %ld linear pixels exceed the int32 index range", NP);
 
-    int v = d.variant >= 0 ? d.variant : pick_variant(d, M, NP);
+    int v = d.variant >= 0 ? d.variant : pick_variant(d, M);
     if (v < 0 || v >= g_nvariants) ND_FAIL(ND_EINVAL, "conv: unknown variant %d", v);
     const Variant &V = g_variants[v];
     if (V.taps != taps || V.up != up) ND_FAIL(ND_EINVAL, "conv: variant %s does not match layer kind %d", V.name, d.kind);
@@ -288,6 +381,8 @@ int nd_launch_conv_f32(const ConvDesc &d, hipStream_t stream) {
     p.act = d.act;
     p.slope = d.slope;
     p.slope_dev = d.slope_dev;
+    static const int ablate = getenv("NIND_ABLATE") ? atoi(getenv("NIND_ABLATE")) : 0;
+    p.ablate = ablate;
 
     // destination geometry must hold the result
     const int oh = up ? 2 * p.Hv : p.Hv, ow = up ? 2 * p.Wv : p.Wv;
@@ -297,16 +392,28 @@ int nd_launch_conv_f32(const ConvDesc &d, hipStream_t stream) {
                 d.out.pad, d.in.B, oh, ow);
     if (d.out_plane0 + d.cout / 4 > d.out.planes) ND_FAIL(ND_EINVAL, "conv: destination planes overflow");
 
-    const int halo = taps == 9 ? 2 * p.Wb + 2 : 0;
-    const int G = (V.nblk + halo + 63) / 64;
-    const size_t lds = 2 * ((size_t)(V.mblk / 32) * V.kbc * taps * 1024 + (size_t)2 * V.kbc * G * 1024);
-    if (lds > 160 * 1024) ND_FAIL(ND_EINVAL, "conv: %zu B of LDS needed (row width %d too large for variant %s)", lds, p.Wb, V.name);
-    ND_HIP(hipFuncSetAttribute((const void *)V.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const size_t lds = variant_lds(V, p.Wb);
+    if (lds > kMaxLds) ND_FAIL(ND_EINVAL, "conv: %zu B of LDS needed (row width %d too large for variant %s)", lds, p.Wb, V.name);
+    if ((int)lds > g_lds_set[v]) {
+        ND_HIP(hipFuncSetAttribute((const void *)V.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        g_lds_set[v] = (int)lds;
+    }
+    if (!g_num_cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        ND_HIP(hipGetDevice(&dev));
+        ND_HIP(hipGetDeviceProperties(&prop, dev));
+        g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
 
-    // only pixels up to the last valid output need a workgroup
+    // only pixels up to the last valid output need a tile
     const long last = NP - (taps == 9 ? 2L * p.Wb + 2 : 0);
-    dim3 grid((unsigned)((last + V.nblk - 1) / V.nblk), (unsigned)((M + V.mblk - 1) / V.mblk));
-    hipLaunchKernelGGL(V.fn, grid, dim3(V.threads), lds, stream, p);
+    p.n_tiles_n = (int)((last + V.nblk - 1) / V.nblk);
+    p.n_tiles_m = (M + V.mblk - 1) / V.mblk;
+    const long ntiles = (long)p.n_tiles_n * p.n_tiles_m;
+    const int per_cu = lds * 2 <= kMaxLds && V.threads <= 256 ? 2 : 1;
+    const long grid = ntiles < (long)g_num_cus * per_cu ? ntiles : (long)g_num_cus * per_cu;
+    hipLaunchKernelGGL(V.fn, dim3((unsigned)grid), dim3(V.threads), lds, stream, p);
     ND_HIP(hipGetLastError());
     return ND_OK;
 }

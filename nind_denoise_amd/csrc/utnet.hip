@@ -350,7 +350,7 @@ extern "C" int nd_utnet_profile_stack(int funit, int act, int dtype, const void 
         if (step_flops) step_flops[i] = fl;
         if (is_conv) is_conv[i] = st.layer >= 0;
     }
-    for (auto &e : ev) hipEventDestroy(e);
+    for (auto &e : ev) (void)hipEventDestroy(e);
     return rc;
 }
 
@@ -477,6 +477,63 @@ extern "C" int nd_maxpool2_forward(const float *x, int batch, int c, int h, int 
     ND_TRY(nd_launch_maxpool2(in, 0, in.planes, out, s));
     ND_TRY(nd_launch_qp_to_nchw(out, 0, y, c, s));
     return ND_OK;
+}
+
+// Kernel micro-benchmark (tools/bench_layers.py): `iters` launches of one conv layer on pseudo-random data already
+// in the quad-planar layout; reports the mean launch duration from HIP events on `stream`.  Synchronises.
+__global__ void k_fill_random(float *p, size_t n, unsigned seed) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        unsigned h = (unsigned)i * 2654435761u ^ seed;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        p[i] = ((h & 0xFFFF) - 32768.f) * (1.f / 65536.f);
+    }
+}
+
+extern "C" int nd_conv_bench(int kind, int batch, int cin, int cout, int h, int w, int variant, int iters, void *ws,
+                             size_t ws_bytes, void *stream, float *mean_ms) {
+    const size_t need = nd_layer_workspace_bytes(kind, batch, cin, cout, h, w, ND_F32);
+    const size_t wfloats = nd_packed_floats(kind, cin, cout);
+    if (!need) ND_FAIL(ND_EINVAL, "nd_conv_bench: bad shape");
+    const size_t total = need + ((wfloats * 4 + 255) & ~(size_t)255);
+    if (!ws || ws_bytes < total) ND_FAIL(ND_ENOMEM, "nd_conv_bench: workspace %zu B given, %zu B needed", ws_bytes, total);
+    hipStream_t s = (hipStream_t)stream;
+    LayerPlan pl = layer_plan(kind, batch, cin, cout, h, w, (char *)ws);
+    float *wpk = (float *)((char *)ws + need);
+    hipLaunchKernelGGL(k_fill_random, dim3(2048), dim3(256), 0, s, (float *)ws, need / 4, 12345u);
+    hipLaunchKernelGGL(k_fill_random, dim3(1024), dim3(256), 0, s, wpk, wfloats, 777u);
+    ConvDesc d;
+    d.kind = kind;
+    d.act = ND_ACT_PRELU;
+    d.slope = 0.2f;
+    d.slope_dev = nullptr;
+    d.cin = cin;
+    d.cout = cout;
+    d.wpk = wpk;
+    d.bias = wpk + (size_t)nd_mtiles(kind, cout) * nd_kblocks(cin) * nd_taps(kind) * 256;
+    d.in = pl.in;
+    d.out = pl.out;
+    d.out_plane0 = 0;
+    d.variant = variant;
+    ND_TRY(nd_launch_conv_f32(d, s));  // warm-up (also validates the variant)
+    hipEvent_t e0, e1;
+    ND_HIP(hipEventCreate(&e0));
+    ND_HIP(hipEventCreate(&e1));
+    ND_HIP(hipEventRecord(e0, s));
+    int rc = ND_OK;
+    for (int i = 0; i < iters && rc == ND_OK; ++i) rc = nd_launch_conv_f32(d, s);
+    (void)hipEventRecord(e1, s);
+    if (hipStreamSynchronize(s) != hipSuccess && rc == ND_OK) {
+        nd_set_error("nd_conv_bench: stream failed");
+        rc = ND_EHIP;
+    }
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (mean_ms) *mean_ms = ms / (iters > 0 ? iters : 1);
+    return rc;
 }
 
 extern "C" int nd_num_conv_variants(void) { return nd_conv_variant_count(); }

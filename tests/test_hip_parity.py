@@ -145,7 +145,7 @@ def test_every_conv_variant(dev):
     tested = 0
     for v in range(lib.nd_num_conv_variants()):
         name = lib.nd_conv_variant_name(v).decode()
-        if name.endswith("_uptrue"):
+        if "_uptrue" in name:
             y = layer_forward(dev, "convT2s2", x, up_w, b[:32], "none", variant=v)
             ref = F.conv_transpose2d(x, up_w, b[:32], stride=2)
         else:
