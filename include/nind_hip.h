@@ -90,6 +90,14 @@ size_t nd_utnet_workspace_bytes(int funit, int cs, int batch, int dtype);
 int nd_utnet_workspace_init(void *workspace, size_t workspace_bytes, int funit, int cs, int batch, int dtype,
                             void *stream);
 
+/* Non-square inputs (the --whole_image branch, denoise_image.py:110-128): h and w must each be of the form 16k+56. */
+size_t nd_utnet_workspace_bytes_hw(int funit, int h, int w, int batch, int dtype);
+int nd_utnet_workspace_init_hw(void *workspace, size_t workspace_bytes, int funit, int h, int w, int batch, int dtype,
+                               void *stream);
+int nd_utnet_forward_hw(int funit, int act, int dtype, const void *packed_dev,
+                        const float *x_nchw, float *y_nchw, int batch, int h, int w,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
 /* UtNet.forward (UtNet.py:97-109): x_nchw [batch,3,cs,cs] -> y_nchw [batch,3,cs,cs], both float32 in HBM. */
 int nd_utnet_forward(int funit, int act, int dtype, const void *packed_dev,
                      const float *x_nchw, float *y_nchw, int batch, int cs,

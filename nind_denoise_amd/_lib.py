@@ -37,6 +37,9 @@ _SIGNATURES = {
     "nd_utnet_pack_weights": (c_int, [c_int, c_int, POINTER(c_void_p), c_int, c_void_p, c_size_t]),
     "nd_utnet_workspace_bytes": (c_size_t, [c_int] * 4),
     "nd_utnet_workspace_init": (c_int, [c_void_p, c_size_t] + [c_int] * 4 + [c_void_p]),
+    "nd_utnet_workspace_bytes_hw": (c_size_t, [c_int] * 5),
+    "nd_utnet_workspace_init_hw": (c_int, [c_void_p, c_size_t] + [c_int] * 5 + [c_void_p]),
+    "nd_utnet_forward_hw": (c_int, [c_int] * 3 + [c_void_p] * 3 + [c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "nd_utnet_forward": (c_int, [c_int] * 3 + [c_void_p] * 3 + [c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "nd_utnet_denoise_tiles": (c_int, [c_int] * 3 + [c_void_p] * 3 + [c_int] * 8 + [c_void_p, c_size_t, c_void_p]),
     "nd_utnet_flops": (c_double, [c_int, c_int]),

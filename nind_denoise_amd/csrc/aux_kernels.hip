@@ -279,26 +279,27 @@ int nd_launch_qp_to_nchw(const QpBuf &src, int plane0, float *y, int C, hipStrea
     return ND_OK;
 }
 
-// x [B,3,S,S] -> ReflectionPad2d(2) (UtNet.py:27,98) -> plane 0 of the first-layer input [(S+4)^2]
-__global__ void k_reflect_pack(const float *__restrict__ x, int S, f32x4 *__restrict__ dst) {
-    const int Sb = S + 4;
+// x [B,3,H,W] -> ReflectionPad2d(2) (UtNet.py:27,98) -> plane 0 of the first-layer input [(H+4) x (W+4)]
+__global__ void k_reflect_pack(const float *__restrict__ x, int H, int W, f32x4 *__restrict__ dst) {
+    const int Hb = H + 4, Wb = W + 4;
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     const int v = blockIdx.y, b = blockIdx.z;
-    if (u >= Sb) return;
-    const int qx = reflect_nr(u - 2, S), qy = reflect_nr(v - 2, S);
-    const float *s = x + ((size_t)b * 3 * S + qy) * S + qx;
+    if (u >= Wb) return;
+    const int qx = reflect_nr(u - 2, W), qy = reflect_nr(v - 2, H);
+    const size_t plane = (size_t)H * W;
+    const float *s = x + ((size_t)b * 3 * H + qy) * W + qx;
     f32x4 o;
     o[0] = s[0];
-    o[1] = s[(size_t)S * S];
-    o[2] = s[2 * (size_t)S * S];
+    o[1] = s[plane];
+    o[2] = s[2 * plane];
     o[3] = 0.f;
-    dst[((size_t)b * Sb + v) * Sb + u] = o;
+    dst[((size_t)b * Hb + v) * Wb + u] = o;
 }
 
-int nd_launch_reflect_pack(const float *x, int B, int S, const QpBuf &dst, hipStream_t s) {
-    if (dst.Hb != S + 4 || dst.Wb != S + 4 || dst.pad != 0 || B > dst.B) ND_FAIL(ND_EINVAL, "reflect_pack: bad destination");
-    dim3 grid((S + 4 + 255) / 256, S + 4, B);
-    hipLaunchKernelGGL(k_reflect_pack, grid, dim3(256), 0, s, x, S, (f32x4 *)dst.base);
+int nd_launch_reflect_pack(const float *x, int B, int H, int W, const QpBuf &dst, hipStream_t s) {
+    if (dst.Hb != H + 4 || dst.Wb != W + 4 || dst.pad != 0 || B > dst.B) ND_FAIL(ND_EINVAL, "reflect_pack: bad destination");
+    dim3 grid((W + 4 + 255) / 256, H + 4, B);
+    hipLaunchKernelGGL(k_reflect_pack, grid, dim3(256), 0, s, x, H, W, (f32x4 *)dst.base);
     ND_HIP(hipGetLastError());
     return ND_OK;
 }
@@ -350,24 +351,24 @@ __device__ __forceinline__ void dot3(const f32x4 *__restrict__ s, long np, int p
 
 __global__ void k_final1x1(const f32x4 *__restrict__ src, long np, int Hb, int Wb, int planes, int cin,
                            const float *__restrict__ w, const float *__restrict__ bias, int crop, float *__restrict__ y,
-                           int S) {
+                           int H, int W) {
     const int xx = blockIdx.x * blockDim.x + threadIdx.x;
     const int yy = blockIdx.y, b = blockIdx.z;
-    if (xx >= S) return;
+    if (xx >= W) return;
     float o0 = bias[0], o1 = bias[1], o2 = bias[2];
     dot3(src + ((size_t)b * Hb + yy + crop) * Wb + xx + crop, np, planes, w, cin, o0, o1, o2);
-    float *d = y + ((size_t)b * 3 * S + yy) * S + xx;
+    float *d = y + ((size_t)b * 3 * H + yy) * W + xx;
     d[0] = o0;
-    d[(size_t)S * S] = o1;
-    d[2 * (size_t)S * S] = o2;
+    d[(size_t)H * W] = o1;
+    d[2 * (size_t)H * W] = o2;
 }
 
-int nd_launch_final1x1(const QpBuf &src, int cin, const float *w, const float *bias, int crop, float *y, int S,
+int nd_launch_final1x1(const QpBuf &src, int cin, const float *w, const float *bias, int crop, float *y, int H, int W,
                        hipStream_t s) {
-    if (src.pad != 0 || src.Hb != S + 2 * crop || src.Wb != S + 2 * crop) ND_FAIL(ND_EINVAL, "final1x1: bad source geometry");
-    dim3 grid((S + 255) / 256, S, src.B);
+    if (src.pad != 0 || src.Hb != H + 2 * crop || src.Wb != W + 2 * crop) ND_FAIL(ND_EINVAL, "final1x1: bad source geometry");
+    dim3 grid((W + 255) / 256, H, src.B);
     hipLaunchKernelGGL(k_final1x1, grid, dim3(256), 0, s, (const f32x4 *)src.base, src.np(), src.Hb, src.Wb,
-                       (cin + 3) / 4, cin, w, bias, crop, y, S);
+                       (cin + 3) / 4, cin, w, bias, crop, y, H, W);
     ND_HIP(hipGetLastError());
     return ND_OK;
 }

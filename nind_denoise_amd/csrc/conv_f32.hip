@@ -9,8 +9,10 @@
 //
 // GEMM view (per launch):  D[m][p] = sum_{tap,ci} Wp[m][tap,ci] * X[ci][p + off(tap)]
 //   M = output channels (MFMA "A" operand = packed weights), N = linear pixels p of the bordered input buffer
-//   (MFMA "B" operand), K = taps * Cin.  Junk columns (x >= Wvalid, y >= Hvalid) are computed and masked at the store:
-//   that is what makes every N tile a contiguous range and every LDS halo image one contiguous copy.
+//   (MFMA "B" operand), K = taps * Cin.  An N tile enumerates VALID output pixels only (compact index
+//   r = y*Wv + x inside an image); the input pixels they read still form ONE contiguous range of the linear input index,
+//   so the LDS halo image stays one contiguous copy per plane and only the per-lane fragment offset (computed once per
+//   tile) knows about the row / image gaps.
 //
 // MFMA fragment use (f32 32x32x2: lane l supplies A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]):
 //   one ds_read_b128 per operand fetches 4 consecutive channels c..c+3 of channel-quad (2*kb + h), h = lane>>5;
@@ -45,9 +47,11 @@ struct ConvParams {
     f32x4 *out;          // plane 0 of the destination buffer
     long in_plane;       // float4 per input plane
     long out_plane;      // float4 per output plane
-    int NP;              // linear pixels in the input buffer (B*Hb*Wb)
+    int nimg;            // images in the batch
     int P, Wb;           // Hb*Wb, Wb of the input buffer
-    int Hv, Wv;          // valid output rows / cols per image
+    int Hv, Wv, PV;      // valid output rows / cols per image, PV = Hv*Wv
+    int tpi;             // > 0: tiles never cross an image, tpi tiles per image (wide rows); 0: tiles run over the whole batch
+    int G;               // 64-pixel DMA pieces per plane and stage (covers the largest input span of a tile + halo)
     int KB;              // Cin / 8
     int M;               // GEMM rows (Cout, or 4*Cout for the 2x2 stride-2 transpose)
     int cout;            // output channels
@@ -58,7 +62,8 @@ struct ConvParams {
     const float *slope_dev;
     int n_tiles_n;       // N tiles (pixels / NBLK, rounded up)
     int n_tiles_m;       // M tiles (rows / MBLK, rounded up)
-    int ablate;          // diagnostics only (NIND_ABLATE): 1 no DMA, 2 no barrier, 4 no stores, 8 no LDS fragment reads
+    int ablate;          // diagnostics only (NIND_ABLATE): 1 no DMA, 2 no barrier, 4 no stores, 8 no LDS fragment reads,
+                         // 16 no vmcnt wait, 32 DMA of weights only, 64 DMA of activations only
 };
 
 __device__ __forceinline__ void glds16(const void *g, void *l) {
@@ -103,8 +108,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_qp_f32(ConvParams p) {
     const int bid = blockIdx.x;
     const int vb = (nwg % 8 == 0) ? (bid % 8) * (nwg / 8) + bid / 8 : bid;
 
-    const int halo = (TAPS == 9) ? 2 * p.Wb + 2 : 0;
-    const int G = (NBLK + halo + 63) >> 6;   // 64-pixel DMA pieces per channel-quad plane
+    const int G = p.G;
     const int planeB = G * 1024;
     const int stageB = WBYTES + 2 * KBC * planeB;
 
@@ -118,6 +122,36 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_qp_f32(ConvParams p) {
     const int nsteps = my_tiles * nchunks;
     if (nsteps == 0) return;
 
+    // ---- tile geometry: N tile nb covers NBLK consecutive valid pixels (of one image if p.tpi, else of the batch)
+    // (image, compact index) of the l-th pixel of N tile nb; pixels past the end are clamped to the last valid one
+    auto pixel_of = [&](int nb, int l, int &img, int &r) -> bool {
+        bool ok;
+        if (p.tpi) {
+            img = nb / p.tpi;
+            r = (nb - img * p.tpi) * NBLK + l;
+            ok = r < p.PV;
+            r = ok ? r : p.PV - 1;
+        } else {
+            const long g = (long)nb * NBLK + l;
+            const long tot = (long)p.nimg * p.PV;
+            ok = g < tot;
+            const long gc = ok ? g : tot - 1;
+            img = (int)(gc / p.PV);
+            r = (int)(gc - (long)img * p.PV);
+        }
+        return ok;
+    };
+    // linear input index of (image, compact index)
+    auto q_of = [&](int img, int r) -> long {
+        const int y = r / p.Wv;
+        return (long)img * p.P + (long)y * p.Wb + (r - y * p.Wv);
+    };
+    auto tile_q0 = [&](int nb) -> long {   // wave-uniform: input index of the tile's first pixel
+        int img, r;
+        pixel_of(nb, 0, img, r);
+        return q_of(img, r);
+    };
+
     // ---- DMA cursor: walks the same (tile, chunk) stream as the compute loop, NSTAGE-1 steps ahead
     int f_id = vb, f_c = 0, f_stage = 0, issued = 0;
     const float *f_w;
@@ -125,7 +159,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_qp_f32(ConvParams p) {
     auto set_fill_tile = [&](int id) {
         const int nb = id / p.n_tiles_m, mb = id - nb * p.n_tiles_m;   // M tiles of one N tile run back to back
         f_w = p.wpk + (size_t)mb * MTB * p.KB * TAPS * 256 + lane * 4;
-        f_a = p.in + (long)nb * NBLK + lane;
+        f_a = p.in + tile_q0(nb) + lane;
     };
     set_fill_tile(f_id);
     // With two waves per SIMD (NW == 8) only waves 0..3 -- one per SIMD -- issue the DMA: their SIMD partners (waves
@@ -135,12 +169,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_qp_f32(ConvParams p) {
         if (issued >= nsteps) return;
         char *sb = smem + f_stage * stageB;
         if (wave < NFILL && !(p.ablate & 1)) {
+            if (!(p.ablate & 64))
 #pragma unroll
             for (int mt = 0; mt < MTB; ++mt) {
                 const float *src = f_w + ((size_t)mt * p.KB + (size_t)f_c * KBC) * TAPS * 256;
                 char *dst = sb + mt * KBC * TAPS * 1024;
                 for (int q = wave; q < KBC * TAPS; q += NFILL) glds16(src + q * 256, dst + q * 1024);
             }
+            if (!(p.ablate & 32))
 #pragma unroll
             for (int pl = 0; pl < 2 * KBC; ++pl) {
                 const f32x4 *src = f_a + (size_t)(f_c * 2 * KBC + pl) * p.in_plane;
@@ -159,9 +195,23 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_qp_f32(ConvParams p) {
 
     // ---- fragments
     const int aOff = (wm * MR) * KBC * TAPS * 1024 + lane * 16;
-    const int bOff = WBYTES + h * planeB + (wn * NR * 32 + j) * 16;
+    // byte offset of this lane's pixel inside a stage's activation image, for each of the wave's NR pixel groups
+    struct BOff { int v[NR]; };
+    auto lane_offsets = [&](int id) -> BOff {
+        BOff o;
+        const int nb = id / p.n_tiles_m;
+        const long q0 = tile_q0(nb);
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) {
+            int img, r;
+            pixel_of(nb, (wn * NR + nr) * 32 + j, img, r);
+            o.v[nr] = WBYTES + h * planeB + (int)(q_of(img, r) - q0) * 16;
+        }
+        return o;
+    };
+    BOff bOff = lane_offsets(vb), bOffN = bOff;
     f32x4 a[2][MR] = {}, b[2][NR] = {};
-    auto load_frags = [&](int buf, const char *sb, int step) {
+    auto load_frags = [&](int buf, const char *sb, int step, const BOff &bo) {
         if (p.ablate & 8) return;
         const int kbl = step / TAPS, t = step % TAPS;
 #pragma unroll
@@ -169,7 +219,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_qp_f32(ConvParams p) {
             a[buf][mr] = *(const f32x4 *)(sb + aOff + ((mr * KBC + kbl) * TAPS + t) * 1024);
 #pragma unroll
         for (int nr = 0; nr < NR; ++nr)
-            b[buf][nr] = *(const f32x4 *)(sb + bOff + kbl * 2 * planeB + toff[t] + nr * 512);
+            b[buf][nr] = *(const f32x4 *)(sb + bo.v[nr] + kbl * 2 * planeB + toff[t]);
     };
 
     f32x16 acc[MR][NR];
@@ -185,15 +235,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_qp_f32(ConvParams p) {
     // ---- epilogue of one finished tile: bias + activation, float4 stores into the (bordered, concatenated) destination
     auto epilogue = [&](int id, auto generic_act) {
         const int nb = id / p.n_tiles_m, mb = id - nb * p.n_tiles_m;
-        const long n0 = (long)nb * NBLK;
 #pragma unroll
         for (int nr = 0; nr < NR; ++nr) {
-            const long pix = n0 + (wn * NR + nr) * 32 + j;
-            const int bi = (int)(pix / p.P);
-            const int r = (int)(pix - (long)bi * p.P);
-            const int y = r / p.Wb;
-            const int x = r - y * p.Wb;
-            const bool valid = pix < p.NP && y < p.Hv && x < p.Wv;
+            int bi, r;
+            const bool valid = pixel_of(nb, (wn * NR + nr) * 32 + j, bi, r);
+            const int y = r / p.Wv;
+            const int x = r - y * p.Wv;
             const long pbase = UP ? (long)bi * p.Po + (long)(2 * y + p.opad) * p.Wo + (2 * x + p.opad)
                                   : (long)bi * p.Po + (long)(y + p.opad) * p.Wo + (x + p.opad);
 #pragma unroll
@@ -240,23 +287,26 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_qp_f32(ConvParams p) {
     for (int i = 0; i < NSTAGE - 1; ++i) fill_next();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (NSTAGE == 3) load_frags(0, smem, 0);
+    if (NSTAGE == 3) load_frags(0, smem, 0, bOff);
 
     int c_id = vb, c_c = 0, c_stage = 0;
     for (int s = 0; s < nsteps; ++s) {
         // my share of the youngest outstanding DMA was issued one whole step ago
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(p.ablate & 16)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!(p.ablate & 2)) __builtin_amdgcn_s_barrier();
         fill_next();
         const char *sb = smem + c_stage * stageB;
         const int n_stage = (c_stage + 1 == NSTAGE) ? 0 : c_stage + 1;
-        if (NSTAGE == 2) load_frags(0, sb, 0);
+        const bool last_chunk = c_c + 1 == nchunks;
+        // the fragments prefetched at the end of a tile's last chunk belong to the NEXT tile: its lane offsets
+        if (last_chunk && c_id + nwg < ntiles) bOffN = lane_offsets(c_id + nwg);
+        if (NSTAGE == 2) load_frags(0, sb, 0, bOff);
 #pragma unroll
         for (int st = 0; st < STEPS; ++st) {
             if (st + 1 < STEPS)
-                load_frags((st + 1) & 1, sb, st + 1);
-            else if (NSTAGE == 3 && s + 1 < nsteps)
-                load_frags((st + 1) & 1, smem + n_stage * stageB, 0);   // next step's first fragments, before its barrier
+                load_frags((st + 1) & 1, sb, st + 1, bOff);
+            else if (NSTAGE == 3 && s + 1 < nsteps)   // next step's first fragments, before its barrier
+                load_frags((st + 1) & 1, smem + n_stage * stageB, 0, last_chunk ? bOffN : bOff);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -280,6 +330,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_qp_f32(ConvParams p) {
                 epilogue(c_id, std::true_type{});
             c_c = 0;
             c_id += nwg;
+            bOff = bOffN;
         }
     }
 }
@@ -317,10 +368,31 @@ static const int g_nvariants = (int)(sizeof(g_variants) / sizeof(g_variants[0]))
 int nd_conv_variant_count() { return g_nvariants; }
 const char *nd_conv_variant_label(int v) { return (v >= 0 && v < g_nvariants) ? g_variants[v].name : ""; }
 
-static size_t variant_lds(const Variant &V, int Wb) {
-    const int halo = V.taps == 9 ? 2 * Wb + 2 : 0;
-    const int G = (V.nblk + halo + 63) / 64;
+// Largest input span (pixels) of one N tile + 3x3 halo.  cross = tiles may run across image boundaries.
+static int tile_span(const Variant &V, const QpBuf &in, bool cross) {
+    const int taps = V.taps;
+    const int Hv = taps == 9 ? in.Hb - 2 : in.Hb, Wv = taps == 9 ? in.Wb - 2 : in.Wb;
+    const int n = V.nblk;
+    int span = n + (in.Wb - Wv) * ((n - 1) / Wv + 1);
+    if (cross) span += (in.Hb - Hv) * in.Wb * ((n - 1) / (Hv * Wv) + 1);
+    if (taps == 9) span += 2 * in.Wb + 2;
+    return span;
+}
+static size_t lds_for(const Variant &V, int G) {
     return (size_t)V.nstage * ((size_t)(V.mblk / 32) * V.kbc * V.taps * 1024 + (size_t)2 * V.kbc * G * 1024);
+}
+// tiles may cross images when that still fits the LDS (small images: no padding of every image to a tile multiple)
+static size_t variant_lds(const Variant &V, const QpBuf &in, bool *cross_out = nullptr, int *G_out = nullptr) {
+    const size_t kMax = 160 * 1024;
+    int G = (tile_span(V, in, true) + 63) / 64;
+    bool cross = true;
+    if (lds_for(V, G) > kMax) {
+        cross = false;
+        G = (tile_span(V, in, false) + 63) / 64;
+    }
+    if (cross_out) *cross_out = cross;
+    if (G_out) *G_out = G;
+    return lds_for(V, G);
 }
 
 static const size_t kMaxLds = 160 * 1024;
@@ -333,7 +405,7 @@ static int pick_variant(const ConvDesc &d, int M) {
         const int first = M <= 32 ? 4 : 0;
         const int order[] = {first, 0, 1, 2};
         for (int v : order)
-            if (variant_lds(g_variants[v], d.in.Wb) <= kMaxLds) return v;
+            if (variant_lds(g_variants[v], d.in) <= kMaxLds) return v;
         return 2;
     }
     if (KB % 2) return up ? 10 : 7;
@@ -366,11 +438,12 @@ int nd_launch_conv_f32(const ConvDesc &d, hipStream_t stream) {
     p.out = (f32x4 *)d.out.base;
     p.in_plane = d.in.np();
     p.out_plane = d.out.np();
-    p.NP = (int)NP;
+    p.nimg = d.in.B;
     p.P = d.in.Hb * d.in.Wb;
     p.Wb = d.in.Wb;
     p.Hv = taps == 9 ? d.in.Hb - 2 : d.in.Hb;
     p.Wv = taps == 9 ? d.in.Wb - 2 : d.in.Wb;
+    p.PV = p.Hv * p.Wv;
     p.KB = KB;
     p.M = M;
     p.cout = d.cout;
@@ -392,7 +465,8 @@ int nd_launch_conv_f32(const ConvDesc &d, hipStream_t stream) {
                 d.out.pad, d.in.B, oh, ow);
     if (d.out_plane0 + d.cout / 4 > d.out.planes) ND_FAIL(ND_EINVAL, "conv: destination planes overflow");
 
-    const size_t lds = variant_lds(V, p.Wb);
+    bool cross = true;
+    const size_t lds = variant_lds(V, d.in, &cross, &p.G);
     if (lds > kMaxLds) ND_FAIL(ND_EINVAL, "conv: %zu B of LDS needed (row width %d too large for variant %s)", lds, p.Wb, V.name);
     if ((int)lds > g_lds_set[v]) {
         ND_HIP(hipFuncSetAttribute((const void *)V.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -406,9 +480,13 @@ int nd_launch_conv_f32(const ConvDesc &d, hipStream_t stream) {
         g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
 
-    // only pixels up to the last valid output need a tile
-    const long last = NP - (taps == 9 ? 2L * p.Wb + 2 : 0);
-    p.n_tiles_n = (int)((last + V.nblk - 1) / V.nblk);
+    if (cross) {
+        p.tpi = 0;
+        p.n_tiles_n = (int)(((long)p.nimg * p.PV + V.nblk - 1) / V.nblk);
+    } else {
+        p.tpi = (p.PV + V.nblk - 1) / V.nblk;
+        p.n_tiles_n = p.tpi * p.nimg;
+    }
     p.n_tiles_m = (M + V.mblk - 1) / V.mblk;
     const long ntiles = (long)p.n_tiles_n * p.n_tiles_m;
     const int per_cu = lds * 2 <= kMaxLds && V.threads <= 256 ? 2 : 1;

@@ -74,10 +74,10 @@ void nd_pack_layer_f32(int kind, int cin, int cout, const float *w, const float 
 // ------------------------------------------------------------------ auxiliary kernels (aux_kernels.hip)
 int nd_launch_nchw_to_qp(const float *x, int C, const QpBuf &dst, int plane0, hipStream_t s);
 int nd_launch_qp_to_nchw(const QpBuf &src, int plane0, float *y, int C, hipStream_t s);
-int nd_launch_reflect_pack(const float *x_nchw, int B, int S, const QpBuf &dst, hipStream_t s);
+int nd_launch_reflect_pack(const float *x_nchw, int B, int H, int W, const QpBuf &dst, hipStream_t s);
 int nd_launch_maxpool2(const QpBuf &src, int src_plane0, int planes, const QpBuf &dst, hipStream_t s);
-int nd_launch_final1x1(const QpBuf &src, int cin, const float *w, const float *bias, int crop, float *y_nchw, int S,
-                       hipStream_t s);
+int nd_launch_final1x1(const QpBuf &src, int cin, const float *w, const float *bias, int crop, float *y_nchw, int H,
+                       int W, hipStream_t s);
 int nd_launch_final1x1_stitch(const QpBuf &src, int cin, const float *w, const float *bias, int crop, float *canvas,
                               int width, int height, int cs, int ucs, int ol, int tile_begin, int tile_count,
                               hipStream_t s);

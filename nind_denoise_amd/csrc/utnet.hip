@@ -92,12 +92,13 @@ BlobLayout blob_layout(int f) {
 
 bool valid_cs(int cs) { return cs >= 104 && (cs - 56) % 16 == 0; }
 
-int check_net(int funit, int cs, int batch, int dtype) {
+int check_net(int funit, int h, int w, int batch, int dtype) {
     if (dtype != ND_F32) ND_FAIL(ND_EINVAL, "UtNet: unsupported dtype %d", dtype);
     if (funit < 8 || funit % 8) ND_FAIL(ND_EINVAL, "UtNet: funit=%d must be a positive multiple of 8", funit);
-    if (!valid_cs(cs))
-        ND_FAIL(ND_EINVAL, "UtNet: tile size cs=%d is not of the form 16k+56 (104, 120, ..., 248, 264, ..., 504, 520); "
-                           "the reference network rejects it too (sizes of the skip concats do not match)", cs);
+    for (int cs : {h, w})
+        if (!valid_cs(cs))
+            ND_FAIL(ND_EINVAL, "UtNet: tile size %d is not of the form 16k+56 (104, 120, ..., 248, 264, ..., 504, 520); "
+                               "the reference network rejects it too (sizes of the skip concats do not match)", cs);
     if (batch <= 0) ND_FAIL(ND_EINVAL, "UtNet: batch=%d", batch);
     return ND_OK;
 }
@@ -111,23 +112,32 @@ struct Plan {
 };
 
 // cap = batch the workspace was sized for; nimg = images in use (<= cap)
-Plan make_plan(int f, int cs, int cap, int nimg, char *base) {
+Plan make_plan(int f, int ch_, int cw_, int cap, int nimg, char *base) {
     Plan p;
     size_t off = 0;
-    auto add = [&](Buf id, int ch, int size, int pad) {
+    // `size` is the extent of the tensor for a SQUARE cs x cs input; the other dimension follows the same chain
+    auto chain = [](int cs, int which) {
+        const int l1 = cs, l2 = cs / 2 - 4, l3 = l2 / 2 - 4, l4 = l3 / 2 - 4, p4 = l4 / 2;
+        const int v[] = {cs + 4, cs + 2, l1, l1 / 2, l1 / 2 - 2, l2, l2 / 2, l2 / 2 - 2, l3, l3 / 2, l3 / 2 - 2, l4, p4,
+                         p4 - 2, p4, l4 + 2, l4 + 4, l3 + 2, l3 + 4, l2 + 2, l2 + 4, l1 + 2, l1 + 4};
+        return v[which];
+    };
+    auto add = [&](Buf id, int ch, int /*size*/, int pad) {
         QpBuf &q = p.buf[id];
         q.planes = (ch + 3) / 4;
         if (id == X0) q.planes = 2;
         q.B = nimg;
-        q.Hb = q.Wb = size + 2 * pad;
+        q.Hb = chain(ch_, (int)id) + 2 * pad;
+        q.Wb = chain(cw_, (int)id) + 2 * pad;
         q.pad = pad;
         q.pstride = (long)cap * q.Hb * q.Wb;
         q.base = (float *)(base + off);
         // slack: an N tile may read (tile + 3x3 halo) pixels past the last plane
-        const size_t slack = (size_t)(2 * q.Wb + 2 + 512 + 64);
+        const size_t slack = (size_t)(2 * q.Wb + 2 + 2048);
         off += ((size_t)q.planes * q.pstride + slack) * 16;
         off = (off + 255) & ~(size_t)255;
     };
+    const int cs = ch_;
     const int l1 = cs, l2 = cs / 2 - 4, l3 = l2 / 2 - 4, l4 = l3 / 2 - 4, p4 = l4 / 2;
     add(X0, 8, cs + 4, 0);
     add(A1, f, cs + 2, 0);
@@ -249,44 +259,59 @@ extern "C" int nd_utnet_pack_weights(int funit, int dtype, const float *const *t
     return ND_OK;
 }
 
+extern "C" size_t nd_utnet_workspace_bytes_hw(int funit, int h, int w, int batch, int dtype) {
+    if (check_net(funit, h, w, batch, dtype) != ND_OK) return 0;
+    return make_plan(funit, h, w, batch, batch, nullptr).bytes;
+}
 extern "C" size_t nd_utnet_workspace_bytes(int funit, int cs, int batch, int dtype) {
-    if (check_net(funit, cs, batch, dtype) != ND_OK) return 0;
-    return make_plan(funit, cs, batch, batch, nullptr).bytes;
+    return nd_utnet_workspace_bytes_hw(funit, cs, cs, batch, dtype);
 }
 
+extern "C" int nd_utnet_workspace_init_hw(void *ws, size_t ws_bytes, int funit, int h, int w, int batch, int dtype,
+                                          void *stream);
 extern "C" int nd_utnet_workspace_init(void *ws, size_t ws_bytes, int funit, int cs, int batch, int dtype, void *stream) {
-    ND_TRY(check_net(funit, cs, batch, dtype));
-    const size_t need = make_plan(funit, cs, batch, batch, nullptr).bytes;
+    return nd_utnet_workspace_init_hw(ws, ws_bytes, funit, cs, cs, batch, dtype, stream);
+}
+extern "C" int nd_utnet_workspace_init_hw(void *ws, size_t ws_bytes, int funit, int h, int w, int batch, int dtype,
+                                          void *stream) {
+    ND_TRY(check_net(funit, h, w, batch, dtype));
+    const size_t need = make_plan(funit, h, w, batch, batch, nullptr).bytes;
     if (!ws || ws_bytes < need) ND_FAIL(ND_ENOMEM, "UtNet workspace: %zu B given, %zu B needed", ws_bytes, need);
     // zero borders (the implicit padding of the transpose convolutions), the unused input channel plane and the slack
     ND_HIP(hipMemsetAsync(ws, 0, need, (hipStream_t)stream));
     return ND_OK;
 }
 
-static int forward_common(int funit, int act, int dtype, const void *packed, int batch_cap, int nimg, int cs, void *ws,
-                          size_t ws_bytes, Plan *out_plan) {
-    ND_TRY(check_net(funit, cs, batch_cap, dtype));
+static int forward_common(int funit, int act, int dtype, const void *packed, int batch_cap, int nimg, int h, int w,
+                          void *ws, size_t ws_bytes, Plan *out_plan) {
+    ND_TRY(check_net(funit, h, w, batch_cap, dtype));
     if (act < ND_ACT_PRELU || act > ND_ACT_HARDSWISH) ND_FAIL(ND_EINVAL, "UtNet: unknown activation %d", act);
     if (nimg <= 0 || nimg > batch_cap) ND_FAIL(ND_EINVAL, "UtNet: %d images with a workspace batch of %d", nimg, batch_cap);
     if (!packed || !ws) ND_FAIL(ND_EINVAL, "UtNet: null pointer");
     if (((uintptr_t)ws & 15) || ((uintptr_t)packed & 15)) ND_FAIL(ND_EINVAL, "UtNet: workspace / weights must be 16-byte aligned");
-    *out_plan = make_plan(funit, cs, batch_cap, nimg, (char *)ws);
+    *out_plan = make_plan(funit, h, w, batch_cap, nimg, (char *)ws);
     if (ws_bytes < out_plan->bytes) ND_FAIL(ND_ENOMEM, "UtNet workspace: %zu B given, %zu B needed", ws_bytes, out_plan->bytes);
     return ND_OK;
 }
 
+extern "C" int nd_utnet_forward_hw(int funit, int act, int dtype, const void *packed, const float *x, float *y, int batch,
+                                   int h, int w, void *ws, size_t ws_bytes, void *stream);
 extern "C" int nd_utnet_forward(int funit, int act, int dtype, const void *packed, const float *x, float *y, int batch,
                                 int cs, void *ws, size_t ws_bytes, void *stream) {
+    return nd_utnet_forward_hw(funit, act, dtype, packed, x, y, batch, cs, cs, ws, ws_bytes, stream);
+}
+extern "C" int nd_utnet_forward_hw(int funit, int act, int dtype, const void *packed, const float *x, float *y, int batch,
+                                   int h, int w, void *ws, size_t ws_bytes, void *stream) {
     Plan pl;
-    ND_TRY(forward_common(funit, act, dtype, packed, batch, batch, cs, ws, ws_bytes, &pl));
+    ND_TRY(forward_common(funit, act, dtype, packed, batch, batch, h, w, ws, ws_bytes, &pl));
     if (!x || !y) ND_FAIL(ND_EINVAL, "UtNet: null tensor");
     hipStream_t s = (hipStream_t)stream;
     const float *blob = (const float *)packed;
-    ND_TRY(nd_launch_reflect_pack(x, batch, cs, pl.buf[X0], s));
+    ND_TRY(nd_launch_reflect_pack(x, batch, h, w, pl.buf[X0], s));
     ND_TRY(run_stack(funit, act, blob, pl, s));
     const BlobLayout bl = blob_layout(funit);
     const float *fw = blob + bl.off[kNumLayers - 1];
-    ND_TRY(nd_launch_final1x1(pl.buf[T4B], funit, fw, fw + 3 * funit, 2, y, cs, s));
+    ND_TRY(nd_launch_final1x1(pl.buf[T4B], funit, fw, fw + 3 * funit, 2, y, h, w, s));
     return ND_OK;
 }
 
@@ -294,7 +319,7 @@ extern "C" int nd_utnet_denoise_tiles(int funit, int act, int dtype, const void 
                                       int width, int height, int cs, int ucs, int ol, int tile_begin, int tile_count,
                                       int batch, void *ws, size_t ws_bytes, void *stream) {
     Plan pl;
-    ND_TRY(forward_common(funit, act, dtype, packed, batch, tile_count, cs, ws, ws_bytes, &pl));
+    ND_TRY(forward_common(funit, act, dtype, packed, batch, tile_count, cs, cs, ws, ws_bytes, &pl));
     if (!img || !canvas) ND_FAIL(ND_EINVAL, "UtNet: null image");
     hipStream_t s = (hipStream_t)stream;
     const float *blob = (const float *)packed;
@@ -314,7 +339,7 @@ extern "C" int nd_utnet_profile_stack(int funit, int act, int dtype, const void 
                                       size_t ws_bytes, void *stream, float *step_ms, double *step_flops, int *is_conv,
                                       int max_steps) {
     Plan pl;
-    ND_TRY(forward_common(funit, act, dtype, packed, batch, batch, cs, ws, ws_bytes, &pl));
+    ND_TRY(forward_common(funit, act, dtype, packed, batch, batch, cs, cs, ws, ws_bytes, &pl));
     if (max_steps < kNumSteps || !step_ms) ND_FAIL(ND_EINVAL, "nd_utnet_profile_stack: need room for %d steps", kNumSteps);
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t ev[kNumSteps + 1];
@@ -401,7 +426,7 @@ LayerPlan layer_plan(int kind, int B, int cin, int cout, int h, int w, char *bas
     p.in.pad = ipad;
     p.in.pstride = (long)B * p.in.Hb * p.in.Wb;
     p.in.base = (float *)base;
-    size_t off = ((size_t)p.in.planes * p.in.pstride + 2 * p.in.Wb + 2 + 576) * 16;
+    size_t off = ((size_t)p.in.planes * p.in.pstride + 2 * p.in.Wb + 2 + 2048) * 16;
     off = (off + 255) & ~(size_t)255;
     int oh, ow;
     switch (kind) {

@@ -98,7 +98,13 @@ class OneImageDS(torch.utils.data.Dataset):
             # one item: the whole frame with a `pad`-wide symmetric mirror border (denoise_image.py:110-128; the
             # reference's (W+2p, H+2p) allocation is only right for square frames -- H,W are used here)
             p = self.pad
-            ret = torch.nn.functional.pad(self.inimg[None], (p, p, p, p), mode='symmetric')[0] if p else self.inimg
+            if p:
+                def sym(n):   # edge pixel repeated, like np.flip of the adjacent band
+                    i = torch.arange(-p, n + p, device=self.inimg.device)
+                    return torch.where(i < 0, -1 - i, torch.where(i >= n, 2 * n - 1 - i, i))
+                ret = self.inimg[:, sym(self.height)][:, :, sym(self.width)].contiguous()
+            else:
+                ret = self.inimg
             usefuldim = (p, p, self.width + p, self.height + p)
             usefulstart = (p, p)
             return ret, torch.IntTensor(usefuldim), torch.IntTensor(usefulstart)

@@ -93,19 +93,21 @@ class UtNet(nn.Module):
         self._packed = (key, dev_blob)
         return dev_blob
 
-    def workspace(self, cs, batch, device):
-        key = (str(device), int(cs), int(batch))
+    def workspace(self, cs, batch, device, width=None):
+        """Activation workspace for [batch,3,cs,width or cs] inputs (zero borders initialised once, then cached)."""
+        h, w = int(cs), int(cs if width is None else width)
+        key = (str(device), h, w, int(batch))
         ws = self._workspaces.get(key)
         if ws is None:
             lib = _lib.load()
-            nbytes = lib.nd_utnet_workspace_bytes(self.funit, cs, batch, _lib.ND_F32)
+            nbytes = lib.nd_utnet_workspace_bytes_hw(self.funit, h, w, batch, _lib.ND_F32)
             if nbytes == 0:
-                _lib.check(lib.nd_utnet_workspace_init(None, 0, self.funit, cs, batch, _lib.ND_F32, None), "UtNet")
+                _lib.check(lib.nd_utnet_workspace_init_hw(None, 0, self.funit, h, w, batch, _lib.ND_F32, None), "UtNet")
             while len(self._workspaces) >= self.max_cached_workspaces:
                 self._workspaces.pop(next(iter(self._workspaces)))
             ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-            _lib.check(lib.nd_utnet_workspace_init(ws.data_ptr(), nbytes, self.funit, cs, batch, _lib.ND_F32,
-                                                   _lib.stream_ptr(device)), "nd_utnet_workspace_init")
+            _lib.check(lib.nd_utnet_workspace_init_hw(ws.data_ptr(), nbytes, self.funit, h, w, batch, _lib.ND_F32,
+                                                      _lib.stream_ptr(device)), "nd_utnet_workspace_init")
             self._workspaces[key] = ws
         return ws
 
@@ -114,21 +116,22 @@ class UtNet(nn.Module):
         if l.device.type != "cuda":
             raise RuntimeError("nind_denoise_amd.UtNet runs on the MI355X HIP path only (no CPU fallback); "
                                "move the module and its input to the GPU")
-        if l.dim() != 4 or l.size(1) != 3 or l.size(2) != l.size(3):
-            raise ValueError(f"UtNet expects [B,3,S,S], got {tuple(l.shape)}")
-        batch, cs = l.size(0), l.size(2)
-        if not valid_cs(cs):
-            raise ValueError(f"UtNet: tile size {cs} is not of the form 16k+56 (e.g. {nearest_valid_cs(cs)}); "
-                             "the reference network fails on it too")
+        if l.dim() != 4 or l.size(1) != 3:
+            raise ValueError(f"UtNet expects [B,3,H,W], got {tuple(l.shape)}")
+        batch, h, w = l.size(0), l.size(2), l.size(3)
+        for cs in (h, w):
+            if not valid_cs(cs):
+                raise ValueError(f"UtNet: tile size {cs} is not of the form 16k+56 (e.g. {nearest_valid_cs(cs)}); "
+                                 "the reference network fails on it too")
         x = l.detach().to(torch.float32).contiguous()
         lib = _lib.load()
         with torch.cuda.device(x.device):
             blob = self.packed_weights(x.device)
-            ws = self.workspace(cs, batch, x.device)
+            ws = self.workspace(h, batch, x.device, width=w)
             y = torch.empty_like(x)
-            _lib.check(lib.nd_utnet_forward(self.funit, _lib.ACT[self.activation], _lib.ND_F32, blob.data_ptr(),
-                                            x.data_ptr(), y.data_ptr(), batch, cs, ws.data_ptr(), ws.numel(),
-                                            _lib.stream_ptr(x.device)), "nd_utnet_forward")
+            _lib.check(lib.nd_utnet_forward_hw(self.funit, _lib.ACT[self.activation], _lib.ND_F32, blob.data_ptr(),
+                                               x.data_ptr(), y.data_ptr(), batch, h, w, ws.data_ptr(), ws.numel(),
+                                               _lib.stream_ptr(x.device)), "nd_utnet_forward")
         return y
 
     def flops_per_tile(self, cs):

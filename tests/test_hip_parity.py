@@ -359,3 +359,46 @@ def test_cli_end_to_end(dev, tmp_path):
     assert np.array_equal(t.cpu().numpy(), otiler.gather_tile(frame, grid, grid.size - 1))
     assert tuple(ud.tolist()) == grid.geom(grid.size - 1)[2] and tuple(us.tolist()) == grid.geom(grid.size - 1)[3]
     assert ud.dtype == torch.int32
+
+
+@pytest.mark.parametrize("cs", [504, 520])
+def test_utnet_f64_wide_tiles_vs_oracle(dev, cs):
+    # the shipped default tile (cs=504, denoise_image.py:41) and BASELINE config 4's cs=520: rows too wide for three
+    # LDS stage images, the conv kernel falls back to its 2-stage variants
+    from nind_denoise_amd.networks.UtNet import UtNet
+    from oracle import networks as onet
+    sd = synth.make_utnet_state_dict(funit=64, seed=123)
+    net = UtNet()
+    net.load_state_dict(sd)
+    net = net.eval().to(dev)
+    x = torch.rand(1, 3, cs, cs, generator=torch.Generator().manual_seed(cs))
+    with torch.no_grad():
+        ref = onet.utnet_forward(sd, x)
+    assert_close(net(x.to(dev)), ref, f"f64 cs{cs}")
+
+
+def test_utnet_non_square_and_whole_image(dev):
+    # --whole_image branch (denoise_image.py:110-128): one item = the whole frame with a symmetric mirror border;
+    # the network then sees a non-square input whose sides are each of the form 16k+56
+    from nind_denoise_amd import denoise_image as di
+    from nind_denoise_amd.networks.UtNet import UtNet
+    from oracle import networks as onet
+    sd = synth.make_utnet_state_dict(funit=16, seed=4)
+    net = UtNet(funit=16)
+    net.load_state_dict(sd)
+    net = net.to(dev)
+    x = torch.rand(2, 3, 104, 152, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        ref = onet.utnet_forward(sd, x)
+    assert_close(net(x.to(dev)), ref, "non-square 104x152")
+    frame = synth.make_frame(136, 88, seed=5)              # W=136, H=88 -> padded by 8: 152 x 104
+    ds = di.OneImageDS(frame, None, None, None, whole_image=True, pad=8, device=dev)
+    assert len(ds) == 1
+    t, ud, us = ds[0]
+    assert tuple(t.shape) == (3, 104, 152) and tuple(ud.tolist()) == (8, 8, 144, 96) and tuple(us.tolist()) == (8, 8)
+    want = np.pad(frame, ((0, 0), (8, 8), (8, 8)), mode="symmetric")
+    assert np.array_equal(t.cpu().numpy(), want)
+    y = net(t[None])[0][:, ud[1]:ud[3], ud[0]:ud[2]]
+    with torch.no_grad():
+        ref = onet.utnet_forward(sd, torch.from_numpy(want)[None])[0][:, 8:96, 8:144]
+    assert_close(y, ref, "whole image")
