@@ -121,6 +121,20 @@ int nd_utnet_profile_stack(int funit, int act, int dtype, const void *packed_dev
                            float *step_ms, double *step_flops, int *is_conv, int max_steps);
 const char *nd_utnet_step_name(int i);
 
+/* ---------------------------------------------------------------- UNet (ThirdPartyNets.py:62-169, eval mode)
+ * Same contract as the UtNet entry points; BatchNorm2d running statistics are folded into the convolutions when the
+ * weights are packed (nd_unet_tensor_name enumerates conv weight/bias and BN weight/bias/running_mean/running_var keys).
+ * Any h, w >= 16 (odd sizes go through the reference's F.pad fix-up).  y = sigmoid(outc(...)); `find_noise` is the
+ * caller's x - y. */
+int nd_unet_num_tensors(void);
+const char *nd_unet_tensor_name(int idx);
+size_t nd_unet_packed_bytes(int dtype);
+int nd_unet_pack_weights(int dtype, const float *const *tensors, int n_tensors, void *packed_host, size_t packed_bytes);
+size_t nd_unet_workspace_bytes(int h, int w, int batch, int dtype);
+int nd_unet_workspace_init(void *workspace, size_t workspace_bytes, int h, int w, int batch, int dtype, void *stream);
+int nd_unet_forward(int dtype, const void *packed_dev, const float *x_nchw, float *y_nchw, int batch, int h, int w,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
 /* FLOP per tile by the reference's own accounting, for roofline reports. */
 double nd_utnet_flops(int funit, int cs);
 

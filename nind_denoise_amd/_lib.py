@@ -42,6 +42,13 @@ _SIGNATURES = {
     "nd_utnet_forward_hw": (c_int, [c_int] * 3 + [c_void_p] * 3 + [c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "nd_utnet_forward": (c_int, [c_int] * 3 + [c_void_p] * 3 + [c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "nd_utnet_denoise_tiles": (c_int, [c_int] * 3 + [c_void_p] * 3 + [c_int] * 8 + [c_void_p, c_size_t, c_void_p]),
+    "nd_unet_num_tensors": (c_int, []),
+    "nd_unet_tensor_name": (c_char_p, [c_int]),
+    "nd_unet_packed_bytes": (c_size_t, [c_int]),
+    "nd_unet_pack_weights": (c_int, [c_int, POINTER(c_void_p), c_int, c_void_p, c_size_t]),
+    "nd_unet_workspace_bytes": (c_size_t, [c_int] * 4),
+    "nd_unet_workspace_init": (c_int, [c_void_p, c_size_t] + [c_int] * 4 + [c_void_p]),
+    "nd_unet_forward": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "nd_utnet_flops": (c_double, [c_int, c_int]),
     "nd_utnet_profile_stack": (c_int, [c_int] * 3 + [c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p,
                                                       POINTER(c_float), POINTER(c_double), POINTER(c_int), c_int]),

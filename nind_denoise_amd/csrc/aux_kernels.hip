@@ -351,12 +351,17 @@ __device__ __forceinline__ void dot3(const f32x4 *__restrict__ s, long np, int p
 
 __global__ void k_final1x1(const f32x4 *__restrict__ src, long np, int Hb, int Wb, int planes, int cin,
                            const float *__restrict__ w, const float *__restrict__ bias, int crop, float *__restrict__ y,
-                           int H, int W) {
+                           int H, int W, int sigmoid) {
     const int xx = blockIdx.x * blockDim.x + threadIdx.x;
     const int yy = blockIdx.y, b = blockIdx.z;
     if (xx >= W) return;
     float o0 = bias[0], o1 = bias[1], o2 = bias[2];
     dot3(src + ((size_t)b * Hb + yy + crop) * Wb + xx + crop, np, planes, w, cin, o0, o1, o2);
+    if (sigmoid) {   // UNet head (ThirdPartyNets.py:169)
+        o0 = 1.f / (1.f + expf(-o0));
+        o1 = 1.f / (1.f + expf(-o1));
+        o2 = 1.f / (1.f + expf(-o2));
+    }
     float *d = y + ((size_t)b * 3 * H + yy) * W + xx;
     d[0] = o0;
     d[(size_t)H * W] = o1;
@@ -364,11 +369,11 @@ __global__ void k_final1x1(const f32x4 *__restrict__ src, long np, int Hb, int W
 }
 
 int nd_launch_final1x1(const QpBuf &src, int cin, const float *w, const float *bias, int crop, float *y, int H, int W,
-                       hipStream_t s) {
+                       hipStream_t s, int sigmoid) {
     if (src.pad != 0 || src.Hb != H + 2 * crop || src.Wb != W + 2 * crop) ND_FAIL(ND_EINVAL, "final1x1: bad source geometry");
     dim3 grid((W + 255) / 256, H, src.B);
     hipLaunchKernelGGL(k_final1x1, grid, dim3(256), 0, s, (const f32x4 *)src.base, src.np(), src.Hb, src.Wb,
-                       (cin + 3) / 4, cin, w, bias, crop, y, H, W);
+                       (cin + 3) / 4, cin, w, bias, crop, y, H, W, sigmoid);
     ND_HIP(hipGetLastError());
     return ND_OK;
 }

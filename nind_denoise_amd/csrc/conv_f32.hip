@@ -460,7 +460,10 @@ int nd_launch_conv_f32(const ConvDesc &d, hipStream_t stream) {
     // destination geometry must hold the result
     const int oh = up ? 2 * p.Hv : p.Hv, ow = up ? 2 * p.Wv : p.Wv;
     if (taps == 1 && d.in.pad != 0) ND_FAIL(ND_EINVAL, "conv: 1-tap layers read unbordered buffers only");
-    if (d.out.Hb != oh + 2 * d.out.pad || d.out.Wb != ow + 2 * d.out.pad || d.out.B != d.in.B)
+    // (a 2x2 stride-2 result may be smaller than its destination: UNet's F.pad fix-up for odd sizes, ThirdPartyNets.py:110-118)
+    const bool fits = up ? (d.out.Hb >= oh + 2 * d.out.pad && d.out.Wb >= ow + 2 * d.out.pad)
+                         : (d.out.Hb == oh + 2 * d.out.pad && d.out.Wb == ow + 2 * d.out.pad);
+    if (!fits || d.out.B != d.in.B)
         ND_FAIL(ND_EINVAL, "conv: destination %dx%dx%d(pad %d) does not fit result %dx%dx%d", d.out.B, d.out.Hb, d.out.Wb,
                 d.out.pad, d.in.B, oh, ow);
     if (d.out_plane0 + d.cout / 4 > d.out.planes) ND_FAIL(ND_EINVAL, "conv: destination planes overflow");

@@ -77,7 +77,7 @@ int nd_launch_qp_to_nchw(const QpBuf &src, int plane0, float *y, int C, hipStrea
 int nd_launch_reflect_pack(const float *x_nchw, int B, int H, int W, const QpBuf &dst, hipStream_t s);
 int nd_launch_maxpool2(const QpBuf &src, int src_plane0, int planes, const QpBuf &dst, hipStream_t s);
 int nd_launch_final1x1(const QpBuf &src, int cin, const float *w, const float *bias, int crop, float *y_nchw, int H,
-                       int W, hipStream_t s);
+                       int W, hipStream_t s, int sigmoid = 0);
 int nd_launch_final1x1_stitch(const QpBuf &src, int cin, const float *w, const float *bias, int crop, float *canvas,
                               int width, int height, int cs, int ucs, int ol, int tile_begin, int tile_count,
                               hipStream_t s);

@@ -13,11 +13,12 @@ import os
 
 import torch
 
+from .networks.ThirdPartyNets import UNet
 from .networks.UtNet import UtNet
 
 COMMON_CONFIG_FPATH = os.path.join('configs', 'common_conf_default.yaml')
 
-NETWORKS = {'UtNet': UtNet}
+NETWORKS = {'UtNet': UtNet, 'UNet': UNet}
 
 
 def register_network(name, cls):

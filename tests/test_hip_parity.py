@@ -402,3 +402,40 @@ def test_utnet_non_square_and_whole_image(dev):
     with torch.no_grad():
         ref = onet.utnet_forward(sd, torch.from_numpy(want)[None])[0][:, 8:96, 8:144]
     assert_close(y, ref, "whole image")
+
+
+def test_unet_golden(dev, golden_dir):
+    # BASELINE config 1 (one 256x256 RGB tile through UNet) on the HIP path + an odd size through the F.pad fix-up
+    from nind_denoise_amd.networks.ThirdPartyNets import UNet
+    d = np.load(os.path.join(golden_dir, "unet_256.npz"))
+    sd = synth.make_unet_state_dict(seed=0)
+    assert synth.state_dict_digest(sd) == str(d["sd_digest"])
+    net = UNet()
+    net.load_state_dict(sd, strict=True)
+    net = net.eval().to(dev)
+    assert_close(net(torch.from_numpy(d["x"]).to(dev)), torch.from_numpy(d["y"]), "unet 256")
+    assert_close(net(torch.from_numpy(d["x2"]).to(dev)), torch.from_numpy(d["y2"]), "unet 100x92")
+    with pytest.raises(RuntimeError):
+        net.train()(torch.from_numpy(d["x"]).to(dev))
+
+
+def test_unet_tiled_frame_vs_oracle(dev):
+    # the generic (non-UtNet) path of the device loop: nd_tile_gather -> model -> nd_stitch_add with UNet
+    from nind_denoise_amd import pipeline
+    from nind_denoise_amd.nn_common import Model
+    from oracle import networks as onet
+    from oracle import tiler as otiler
+    sd = synth.make_unet_state_dict(seed=0)
+    net = Model.instantiate_model(network="UNet", device=dev)
+    net.load_state_dict(sd)
+    net.eval()
+    W, H, cs, ucs, ol = 200, 170, 96, 64, 8
+    frame = synth.make_frame(W, H, seed=6)
+
+    def model_fn(x):
+        with torch.no_grad():
+            return onet.unet_forward(sd, torch.from_numpy(x)).numpy()
+
+    ref = otiler.denoise_frame(frame, cs, ucs, ol, model_fn, batch=4)
+    out = pipeline.denoise_frame(net, torch.from_numpy(frame).to(dev), cs, ucs, ol, batch=5)
+    assert_close(out, torch.from_numpy(ref), "unet frame")

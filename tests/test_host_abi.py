@@ -203,3 +203,17 @@ def test_image_codecs_roundtrip(tmp_path):
     assert np.array_equal(imgcodec.read_png(str(tmp_path / "p.png")), x8)
     with pytest.raises(FileNotFoundError):
         np_imgops.img_path_to_np_flt(str(tmp_path / "missing.tif"))
+
+
+def test_unet_module_state_dict_layout():
+    from nind_denoise_amd.networks.ThirdPartyNets import UNet
+    from nind_denoise_amd.nn_common import NETWORKS
+    assert set(NETWORKS) >= {"UtNet", "UNet"}       # the reference only registers UtNet (nn_common.py:12)
+    net = UNet()
+    sd = net.state_dict()
+    ref = synth.make_unet_state_dict(seed=0)
+    assert set(sd) == set(ref) and all(tuple(sd[k].shape) == tuple(ref[k].shape) for k in ref)
+    assert sum(p.numel() for p in net.parameters()) == 14_789_059
+    lib = _lib.load()
+    names = [lib.nd_unet_tensor_name(i).decode() for i in range(lib.nd_unet_num_tensors())]
+    assert set(names) <= set(sd)
