@@ -91,6 +91,28 @@ def conv_stack_profile(net, cs, batch, dev, reps=3):
     return steps
 
 
+def pmc_traffic(cs, batch, funit):
+    """HBM bytes per launch of the dominant kernel (the 3x3 conv_qp_f32 variant) from the committed rocprofv3 PMC passes
+    (FETCH_SIZE and WRITE_SIZE collected in separate runs, gfx950 read correction applied -- profiles/*_pmc_summary.json).
+    Counters cannot be read inside the timed run, so this is null unless a profile of the same configuration exists."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), reverse=True):
+        try:
+            with open(f) as fh:
+                d = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        c = d.get("config", {})
+        if (c.get("cs"), c.get("tiles_per_launch"), c.get("funit")) != (cs, batch, funit):
+            continue
+        for name, v in d.get("kernels", {}).items():
+            if "conv_qp_f32" in name and ", 9, " in name and "hbm_read_bytes_mean" in v:
+                return {"bytes_per_launch": round(v["hbm_read_bytes_mean"] + v["hbm_write_bytes_mean"]),
+                        "read": round(v["hbm_read_bytes_mean"]), "write": round(v["hbm_write_bytes_mean"]),
+                        "source": os.path.relpath(f, ROOT)}
+    return None
+
+
 def cpu_baseline(frame, sd, cs, ucs, ol, n_tiles, threads):
     """The oracle's crop -> UtNet -> stitch on `n_tiles` tiles of the frame (torch CPU fp32, grad mode off)."""
     import numpy as np
@@ -227,7 +249,7 @@ def main():
                 "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                "traffic": None,
+                "traffic": pmc_traffic(cs, b, args.funit),
                 "launches": len([s for s in steps if s["conv"]]),
                 "avg_launch_ms": round(conv_ms / max(1, len([s for s in steps if s["conv"]])), 4),
                 "algorithmic_flop_per_launch_avg": conv_flop / max(1, len([s for s in steps if s["conv"]])),
