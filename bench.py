@@ -249,7 +249,9 @@ def main():
                 "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                "traffic": pmc_traffic(cs, b, args.funit),
+                "traffic": (pmc_traffic(cs, b, args.funit) or {}).get("bytes_per_launch"),
+                "traffic_unit": "HBM bytes per launch of the 3x3 conv_qp_f32 variant (PMC FETCH_SIZE*2 + WRITE_SIZE)",
+                "traffic_detail": pmc_traffic(cs, b, args.funit),
                 "launches": len([s for s in steps if s["conv"]]),
                 "avg_launch_ms": round(conv_ms / max(1, len([s for s in steps if s["conv"]])), 4),
                 "algorithmic_flop_per_launch_avg": conv_flop / max(1, len([s for s in steps if s["conv"]])),
