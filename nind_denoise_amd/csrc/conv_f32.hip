@@ -362,6 +362,7 @@ static const Variant g_variants[] = {
     ND_VARIANT(2, 2, 2, 4, 1, 2, true, 3),   // 9: up, M128 x N256
     ND_VARIANT(2, 2, 1, 8, 1, 1, true, 3),   // 10: up, K chunk of 8 channels
     ND_VARIANT(2, 2, 2, 2, 1, 2, true, 2),   // 11: up, M128 x N128, 4 waves, 2 stages
+    ND_VARIANT(4, 2, 2, 4, 1, 2, true, 3),   // 12: up, M256 x N256, 8 waves x (128x64): activations re-read M/256 times only
 };
 static const int g_nvariants = (int)(sizeof(g_variants) / sizeof(g_variants[0]));
 
@@ -409,7 +410,8 @@ static int pick_variant(const ConvDesc &d, int M) {
         return 2;
     }
     if (KB % 2) return up ? 10 : 7;
-    return up ? 8 : 6;
+    if (up) return M >= 256 ? 12 : 8;
+    return 6;
 }
 
 static int g_num_cus = 0;

@@ -62,8 +62,10 @@ int nd_conv_variant_count();
 const char *nd_conv_variant_label(int v);
 
 // packed size helpers (host)
-// 32-row MFMA tiles, padded to a multiple of 4 so that every workgroup shape (M_blk <= 128) reads packed rows only
-static inline int nd_mtiles(int kind, int cout) { return ((kind == ND_CONVT2S2 ? 4 * cout : cout) + 127) / 128 * 4; }
+// 32-row MFMA tiles, padded so that every workgroup shape (M_blk <= 128, 256 for the 2x2 stride-2 layers) reads packed rows only
+static inline int nd_mtiles(int kind, int cout) {
+    return kind == ND_CONVT2S2 ? (4 * cout + 255) / 256 * 8 : (cout + 127) / 128 * 4;   // up layers use 256-row workgroup tiles
+}
 static inline int nd_taps(int kind) { return (kind == ND_CONV3 || kind == ND_CONVT3) ? 9 : 1; }
 static inline int nd_kblocks(int cin) { return (cin + 7) / 8; }
 static inline size_t nd_packed_floats(int kind, int cin, int cout) {

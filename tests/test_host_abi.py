@@ -65,7 +65,7 @@ def test_tile_geometry_errors():
 def _ref_pack(kind, cin, cout, w):
     taps = 9 if kind in ("conv3", "convT3") else 1
     M = 4 * cout if kind == "convT2s2" else cout
-    MT, KB = (M + 127) // 128 * 4, (cin + 7) // 8
+    MT, KB = ((M + 255) // 256 * 8 if kind == "convT2s2" else (M + 127) // 128 * 4), (cin + 7) // 8
     out = np.zeros((MT, KB, taps, 64, 4), dtype=np.float32)
     for mt in range(MT):
         for lane in range(64):
