@@ -26,7 +26,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+# /opt/skills/guides/MI355X_MICROARCH.md: "Peak FP32 (matrix)" 157.3 TFLOP/s; "Peak BF16/FP16 MFMA ~2.5 PF dense"
+PEAK_MFMA_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0}
 
 
 def log(msg):
@@ -62,6 +63,9 @@ def parse():
     ap.add_argument("--ucs", type=int, default=200)
     ap.add_argument("--ol", type=int, default=64)
     ap.add_argument("--funit", type=int, default=64)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"],
+                    help="storage inside the conv stack; f32 is the headline configuration (exact-fp32 MFMA), bf16 / f16 are "
+                         "BASELINE configs 3 / 4 (16-bit storage, fp32 accumulate)")
     ap.add_argument("--cpu-sample-tiles", type=int, default=0, help="0: sized for ~15 s of CPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -82,7 +86,7 @@ def conv_stack_profile(net, cs, batch, dev, reps=3):
     isc = (ctypes.c_int * n)()
     runs = []
     for _ in range(reps + 1):
-        _lib.check(lib.nd_utnet_profile_stack(net.funit, _lib.ACT[net.activation], _lib.ND_F32, blob.data_ptr(), batch, cs,
+        _lib.check(lib.nd_utnet_profile_stack(net.funit, _lib.ACT[net.activation], _lib.DTYPE[net.compute_dtype], blob.data_ptr(), batch, cs,
                                               ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev), ms, fl, isc, n))
         runs.append(list(ms))
     med = np.median(np.array(runs[1:]), axis=0)
@@ -161,7 +165,7 @@ def main():
     sd = synth.make_utnet_state_dict(funit=args.funit, seed=123)
     net = UtNet(funit=args.funit)
     net.load_state_dict(sd)
-    net = net.eval().to(dev)
+    net = net.eval().to(dev).set_compute_dtype(args.dtype)
     blob = net.packed_weights(dev)
     if world > 1:
         dist.broadcast(blob, src=0)  # one-time weight broadcast (rank 0 is the model owner)
@@ -220,10 +224,11 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": args.dtype,
         "data": "synthetic",
         "config": {
-            "workload": f"configs[1]: one {W}x{H} ({mp:.1f} MP) fp32 frame per step, UtNet(funit={args.funit},PReLU) random-init "
+            "workload": f"configs[{1 if args.dtype == 'f32' else 2 if args.dtype == 'bf16' else 3}]: one {W}x{H} ({mp:.1f} MP) fp32 frame per step, "
+                        f"{args.dtype} storage in the conv stack (fp32 accumulate), UtNet(funit={args.funit},PReLU) random-init "
                         f"(seed 123), cs={cs} (nearest valid to 256; the reference rejects 256) ucs={ucs} ol={ol} -> {total} tiles, "
                         f"tiles per conv-stack launch {args.batch}, crop->infer->stitch device resident",
             "tiles_per_frame": total,
@@ -244,14 +249,14 @@ def main():
             achieved = conv_flop / (conv_ms * 1e-3) / 1e12
             out["roofline"] = {
                 "bound": "mfma",
-                "kernel": "conv_qp_f32 (22 launches per tile batch: every 3x3 / transposed conv of UtNet)",
+                "kernel": f"conv_qp<{args.dtype}> (22 launches per tile batch: every 3x3 / transposed conv of UtNet)",
                 "achieved": round(achieved, 3),
-                "peak": PEAK_F32_MFMA_TFLOPS,
+                "peak": PEAK_MFMA_TFLOPS[args.dtype],
                 "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                "traffic": (pmc_traffic(cs, b, args.funit) or {}).get("bytes_per_launch"),
-                "traffic_unit": "HBM bytes per launch of the 3x3 conv_qp_f32 variant (PMC FETCH_SIZE*2 + WRITE_SIZE)",
-                "traffic_detail": pmc_traffic(cs, b, args.funit),
+                "frac": round(achieved / PEAK_MFMA_TFLOPS[args.dtype], 4),
+                "traffic": (pmc_traffic(cs, b, args.funit) or {}).get("bytes_per_launch") if args.dtype == "f32" else None,
+                "traffic_unit": "HBM bytes per launch of the 3x3 conv_qp variant (PMC FETCH_SIZE*2 + WRITE_SIZE)",
+                "traffic_detail": pmc_traffic(cs, b, args.funit) if args.dtype == "f32" else None,
                 "launches": len([s for s in steps if s["conv"]]),
                 "avg_launch_ms": round(conv_ms / max(1, len([s for s in steps if s["conv"]])), 4),
                 "algorithmic_flop_per_launch_avg": conv_flop / max(1, len([s for s in steps if s["conv"]])),

@@ -45,7 +45,9 @@ typedef enum nd_layer_kind {
 } nd_layer_kind;
 
 typedef enum nd_dtype {
-    ND_F32 = 0            /* fp32 storage, fp32 MFMA (v_mfma_f32_32x32x2_f32), exact-fp32 products */
+    ND_F32 = 0,           /* fp32 storage, fp32 MFMA (v_mfma_f32_32x32x2_f32), exact-fp32 products            */
+    ND_BF16 = 1,          /* bf16 storage of activations + weights, fp32 accumulate (v_mfma_f32_32x32x16_bf16) */
+    ND_F16 = 2            /* fp16 storage of activations + weights, fp32 accumulate (v_mfma_f32_32x32x16_f16)  */
 } nd_dtype;
 
 int nd_version(void);
@@ -155,7 +157,7 @@ int nd_maxpool2_forward(const float *x_nchw, int batch, int c, int h, int w, flo
 /* Kernel micro-benchmark: `iters` launches of one conv layer (variant -1 = automatic choice) on pseudo-random
  * quad-planar data carved from `workspace` (nd_layer_workspace_bytes + nd_layer_packed_bytes + 256 B); mean launch
  * duration from HIP events on `stream`.  Synchronises the stream. */
-int nd_conv_bench(int kind, int batch, int cin, int cout, int h, int w, int variant, int iters,
+int nd_conv_bench(int kind, int dtype, int batch, int cin, int cout, int h, int w, int variant, int iters,
                   void *workspace, size_t workspace_bytes, void *stream, float *mean_ms);
 
 /* Name and average duration bookkeeping for bench.py: number of conv-kernel variants compiled in. */

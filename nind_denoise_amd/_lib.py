@@ -9,7 +9,8 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_size_t, c_void
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnind_hip.so")
 
-ND_F32 = 0
+ND_F32, ND_BF16, ND_F16 = 0, 1, 2
+DTYPE = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "f16": 2, "fp16": 2, "float16": 2}
 ACT = {"none": 0, "PReLU": 1, "ELU": 2, "Hardswish": 3}
 KIND = {"conv3": 0, "convT3": 1, "convT2s2": 2, "conv1": 3}
 
@@ -59,7 +60,7 @@ _SIGNATURES = {
     "nd_layer_forward": (c_int, [c_int, c_int, c_float, c_int, c_void_p, c_void_p] + [c_int] * 5
                          + [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "nd_maxpool2_forward": (c_int, [c_void_p] + [c_int] * 4 + [c_void_p, c_void_p, c_size_t, c_void_p]),
-    "nd_conv_bench": (c_int, [c_int] * 8 + [c_void_p, c_size_t, c_void_p, POINTER(c_float)]),
+    "nd_conv_bench": (c_int, [c_int] * 9 + [c_void_p, c_size_t, c_void_p, POINTER(c_float)]),
     "nd_num_conv_variants": (c_int, []),
     "nd_conv_variant_name": (c_char_p, [c_int]),
 }

@@ -4,6 +4,20 @@
 #include "nd_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// One 16-byte plane element = the channels of one pixel in one plane: 4 x fp32, 8 x bf16 or 8 x fp16.
+template <int DT> struct Elem { typedef f32x4 vec; static constexpr int N = 4; typedef float scalar; };
+template <> struct Elem<ND_BF16> { typedef bf16x8 vec; static constexpr int N = 8; typedef __bf16 scalar; };
+template <> struct Elem<ND_F16> { typedef f16x8 vec; static constexpr int N = 8; typedef _Float16 scalar; };
+#define ND_DISPATCH_DT(dt, CALL)                     \
+    switch (dt) {                                    \
+        case ND_F32: { constexpr int DT = ND_F32; CALL; break; }   \
+        case ND_BF16: { constexpr int DT = ND_BF16; CALL; break; } \
+        case ND_F16: { constexpr int DT = ND_F16; CALL; break; }   \
+        default: ND_FAIL(ND_EINVAL, "unsupported storage type %d", dt); \
+    }
 
 // ------------------------------------------------------------------ tile geometry (OneImageDS, denoise_image.py:100-143)
 struct TileGeo {
@@ -104,7 +118,8 @@ extern "C" int nd_tile_gather(const float *img, int W, int H, int cs, int ucs, i
 }
 
 // fused: gather(+symmetric mirror) -> ReflectionPad2d(2) -> quad-planar first-layer input (plane 0 = r,g,b,0)
-__global__ void k_gather_pack(const float *__restrict__ img, TileGeo g, int tile_begin, f32x4 *__restrict__ dst, int Sb) {
+template <int DT>
+__global__ void k_gather_pack(const float *__restrict__ img, TileGeo g, int tile_begin, typename Elem<DT>::vec *__restrict__ dst, int Sb) {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;  // column in the reflect-padded tile
     const int v = blockIdx.y;
     const int t = blockIdx.z;
@@ -116,11 +131,10 @@ __global__ void k_gather_pack(const float *__restrict__ img, TileGeo g, int tile
     const int sy = mirror_sym(yi * g.stride - g.pad + qy, g.H);
     const size_t plane = (size_t)g.W * g.H;
     const float *s = img + (size_t)sy * g.W + sx;
-    f32x4 o;
-    o[0] = s[0];
-    o[1] = s[plane];
-    o[2] = s[2 * plane];
-    o[3] = 0.f;
+    typename Elem<DT>::vec o = {};
+    o[0] = (typename Elem<DT>::scalar)s[0];
+    o[1] = (typename Elem<DT>::scalar)s[plane];
+    o[2] = (typename Elem<DT>::scalar)s[2 * plane];
     dst[((size_t)t * Sb + v) * Sb + u] = o;
 }
 
@@ -132,7 +146,8 @@ int nd_launch_gather_pack(const float *img, int W, int H, int cs, int ucs, int o
         ND_FAIL(ND_EINVAL, "gather_pack: bad tile range [%d,+%d)", tile_begin, tile_count);
     if (dst.Hb != cs + 4 || dst.Wb != cs + 4 || dst.pad != 0) ND_FAIL(ND_EINVAL, "gather_pack: destination is not (cs+4)^2");
     dim3 grid((cs + 4 + 255) / 256, cs + 4, tile_count);
-    hipLaunchKernelGGL(k_gather_pack, grid, dim3(256), 0, s, img, g, tile_begin, (f32x4 *)dst.base, cs + 4);
+    ND_DISPATCH_DT(dst.dt, hipLaunchKernelGGL(k_gather_pack<DT>, grid, dim3(256), 0, s, img, g, tile_begin,
+                                              (typename Elem<DT>::vec *)dst.base, cs + 4));
     ND_HIP(hipGetLastError());
     return ND_OK;
 }
@@ -232,55 +247,62 @@ extern "C" int nd_stitch_add(float *canvas, int W, int H, int cs, int ucs, int o
 }
 
 // ------------------------------------------------------------------ layout conversion NCHW <-> quad-planar
-__global__ void k_nchw_to_qp(const float *__restrict__ x, int C, int H, int W, f32x4 *__restrict__ dst, long np, int Hb,
-                             int Wb, int pad, int plane0) {
+template <int DT>
+__global__ void k_nchw_to_qp(const float *__restrict__ x, int C, int H, int W, typename Elem<DT>::vec *__restrict__ dst,
+                             long np, int Hb, int Wb, int pad, int plane0) {
+    constexpr int N = Elem<DT>::N;
     const int xx = blockIdx.x * blockDim.x + threadIdx.x;
     const int yy = blockIdx.y;
-    const int q = blockIdx.z % ((C + 3) / 4), b = blockIdx.z / ((C + 3) / 4);
+    const int q = blockIdx.z % ((C + N - 1) / N), b = blockIdx.z / ((C + N - 1) / N);
     if (xx >= W) return;
-    f32x4 o;
+    typename Elem<DT>::vec o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int c = 4 * q + e;
-        o[e] = c < C ? x[(((size_t)b * C + c) * H + yy) * W + xx] : 0.f;
+    for (int e = 0; e < N; ++e) {
+        const int c = N * q + e;
+        o[e] = (typename Elem<DT>::scalar)(c < C ? x[(((size_t)b * C + c) * H + yy) * W + xx] : 0.f);
     }
     dst[(size_t)(plane0 + q) * np + ((size_t)b * Hb + yy + pad) * Wb + xx + pad] = o;
 }
 
 int nd_launch_nchw_to_qp(const float *x, int C, const QpBuf &dst, int plane0, hipStream_t s) {
     const int H = dst.Hb - 2 * dst.pad, W = dst.Wb - 2 * dst.pad;
-    dim3 grid((W + 255) / 256, H, dst.B * ((C + 3) / 4));
-    hipLaunchKernelGGL(k_nchw_to_qp, grid, dim3(256), 0, s, x, C, H, W, (f32x4 *)dst.base, dst.np(), dst.Hb, dst.Wb,
-                       dst.pad, plane0);
+    const int n = nd_cpp(dst.dt);
+    dim3 grid((W + 255) / 256, H, dst.B * ((C + n - 1) / n));
+    ND_DISPATCH_DT(dst.dt, hipLaunchKernelGGL(k_nchw_to_qp<DT>, grid, dim3(256), 0, s, x, C, H, W,
+                                              (typename Elem<DT>::vec *)dst.base, dst.np(), dst.Hb, dst.Wb, dst.pad, plane0));
     ND_HIP(hipGetLastError());
     return ND_OK;
 }
 
-__global__ void k_qp_to_nchw(const f32x4 *__restrict__ src, long np, int Hb, int Wb, int pad, int plane0,
+template <int DT>
+__global__ void k_qp_to_nchw(const typename Elem<DT>::vec *__restrict__ src, long np, int Hb, int Wb, int pad, int plane0,
                              float *__restrict__ y, int C, int H, int W) {
+    constexpr int N = Elem<DT>::N;
     const int xx = blockIdx.x * blockDim.x + threadIdx.x;
     const int yy = blockIdx.y;
-    const int q = blockIdx.z % ((C + 3) / 4), b = blockIdx.z / ((C + 3) / 4);
+    const int q = blockIdx.z % ((C + N - 1) / N), b = blockIdx.z / ((C + N - 1) / N);
     if (xx >= W) return;
-    const f32x4 v = src[(size_t)(plane0 + q) * np + ((size_t)b * Hb + yy + pad) * Wb + xx + pad];
+    const typename Elem<DT>::vec v = src[(size_t)(plane0 + q) * np + ((size_t)b * Hb + yy + pad) * Wb + xx + pad];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int c = 4 * q + e;
-        if (c < C) y[(((size_t)b * C + c) * H + yy) * W + xx] = v[e];
+    for (int e = 0; e < N; ++e) {
+        const int c = N * q + e;
+        if (c < C) y[(((size_t)b * C + c) * H + yy) * W + xx] = (float)v[e];
     }
 }
 
 int nd_launch_qp_to_nchw(const QpBuf &src, int plane0, float *y, int C, hipStream_t s) {
     const int H = src.Hb - 2 * src.pad, W = src.Wb - 2 * src.pad;
-    dim3 grid((W + 255) / 256, H, src.B * ((C + 3) / 4));
-    hipLaunchKernelGGL(k_qp_to_nchw, grid, dim3(256), 0, s, (const f32x4 *)src.base, src.np(), src.Hb, src.Wb, src.pad,
-                       plane0, y, C, H, W);
+    const int n = nd_cpp(src.dt);
+    dim3 grid((W + 255) / 256, H, src.B * ((C + n - 1) / n));
+    ND_DISPATCH_DT(src.dt, hipLaunchKernelGGL(k_qp_to_nchw<DT>, grid, dim3(256), 0, s, (const typename Elem<DT>::vec *)src.base,
+                                              src.np(), src.Hb, src.Wb, src.pad, plane0, y, C, H, W));
     ND_HIP(hipGetLastError());
     return ND_OK;
 }
 
 // x [B,3,H,W] -> ReflectionPad2d(2) (UtNet.py:27,98) -> plane 0 of the first-layer input [(H+4) x (W+4)]
-__global__ void k_reflect_pack(const float *__restrict__ x, int H, int W, f32x4 *__restrict__ dst) {
+template <int DT>
+__global__ void k_reflect_pack(const float *__restrict__ x, int H, int W, typename Elem<DT>::vec *__restrict__ dst) {
     const int Hb = H + 4, Wb = W + 4;
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     const int v = blockIdx.y, b = blockIdx.z;
@@ -288,75 +310,82 @@ __global__ void k_reflect_pack(const float *__restrict__ x, int H, int W, f32x4 
     const int qx = reflect_nr(u - 2, W), qy = reflect_nr(v - 2, H);
     const size_t plane = (size_t)H * W;
     const float *s = x + ((size_t)b * 3 * H + qy) * W + qx;
-    f32x4 o;
-    o[0] = s[0];
-    o[1] = s[plane];
-    o[2] = s[2 * plane];
-    o[3] = 0.f;
+    typename Elem<DT>::vec o = {};
+    o[0] = (typename Elem<DT>::scalar)s[0];
+    o[1] = (typename Elem<DT>::scalar)s[plane];
+    o[2] = (typename Elem<DT>::scalar)s[2 * plane];
     dst[((size_t)b * Hb + v) * Wb + u] = o;
 }
 
 int nd_launch_reflect_pack(const float *x, int B, int H, int W, const QpBuf &dst, hipStream_t s) {
     if (dst.Hb != H + 4 || dst.Wb != W + 4 || dst.pad != 0 || B > dst.B) ND_FAIL(ND_EINVAL, "reflect_pack: bad destination");
     dim3 grid((W + 4 + 255) / 256, H + 4, B);
-    hipLaunchKernelGGL(k_reflect_pack, grid, dim3(256), 0, s, x, H, W, (f32x4 *)dst.base);
+    ND_DISPATCH_DT(dst.dt, hipLaunchKernelGGL(k_reflect_pack<DT>, grid, dim3(256), 0, s, x, H, W, (typename Elem<DT>::vec *)dst.base));
     ND_HIP(hipGetLastError());
     return ND_OK;
 }
 
 // ------------------------------------------------------------------ MaxPool2d(2) (UtNet.py:34), quad-planar
-__global__ void k_maxpool2(const f32x4 *__restrict__ src, long snp, int sHb, int sWb, int spad, int splane0,
-                           f32x4 *__restrict__ dst, long dnp, int dHb, int dWb, int dpad, int Ho, int Wo, int B) {
+template <int DT>
+__global__ void k_maxpool2(const typename Elem<DT>::vec *__restrict__ src, long snp, int sHb, int sWb, int spad, int splane0,
+                           typename Elem<DT>::vec *__restrict__ dst, long dnp, int dHb, int dWb, int dpad, int Ho, int Wo, int B) {
+    typedef typename Elem<DT>::vec V;
     const int xx = blockIdx.x * blockDim.x + threadIdx.x;
     const int yy = blockIdx.y;
     const int b = blockIdx.z % B, q = blockIdx.z / B;
     if (xx >= Wo) return;
-    const f32x4 *s = src + (size_t)(splane0 + q) * snp + ((size_t)b * sHb + 2 * yy + spad) * sWb + 2 * xx + spad;
-    const f32x4 a = s[0], c = s[1], d = s[sWb], e = s[sWb + 1];
-    f32x4 o;
+    const V *s = src + (size_t)(splane0 + q) * snp + ((size_t)b * sHb + 2 * yy + spad) * sWb + 2 * xx + spad;
+    const V a = s[0], c = s[1], d = s[sWb], e = s[sWb + 1];
+    V o;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) o[k] = fmaxf(fmaxf(a[k], c[k]), fmaxf(d[k], e[k]));
+    for (int k = 0; k < Elem<DT>::N; ++k)
+        o[k] = (typename Elem<DT>::scalar)fmaxf(fmaxf((float)a[k], (float)c[k]), fmaxf((float)d[k], (float)e[k]));
     dst[(size_t)q * dnp + ((size_t)b * dHb + yy + dpad) * dWb + xx + dpad] = o;
 }
 
 int nd_launch_maxpool2(const QpBuf &src, int src_plane0, int planes, const QpBuf &dst, hipStream_t s) {
     const int Hi = src.Hb - 2 * src.pad, Wi = src.Wb - 2 * src.pad;
     const int Ho = Hi / 2, Wo = Wi / 2;
-    if (dst.Hb - 2 * dst.pad != Ho || dst.Wb - 2 * dst.pad != Wo || dst.B != src.B || dst.planes < planes)
+    if (dst.Hb - 2 * dst.pad != Ho || dst.Wb - 2 * dst.pad != Wo || dst.B != src.B || dst.planes < planes || dst.dt != src.dt)
         ND_FAIL(ND_EINVAL, "maxpool2: destination does not fit %dx%d", Ho, Wo);
     dim3 grid((Wo + 127) / 128, Ho, src.B * planes);
-    hipLaunchKernelGGL(k_maxpool2, grid, dim3(128), 0, s, (const f32x4 *)src.base, src.np(), src.Hb, src.Wb, src.pad,
-                       src_plane0, (f32x4 *)dst.base, dst.np(), dst.Hb, dst.Wb, dst.pad, Ho, Wo, src.B);
+    ND_DISPATCH_DT(src.dt, hipLaunchKernelGGL(k_maxpool2<DT>, grid, dim3(128), 0, s, (const typename Elem<DT>::vec *)src.base,
+                                              src.np(), src.Hb, src.Wb, src.pad, src_plane0, (typename Elem<DT>::vec *)dst.base,
+                                              dst.np(), dst.Hb, dst.Wb, dst.pad, Ho, Wo, src.B));
     ND_HIP(hipGetLastError());
     return ND_OK;
 }
 
 // ------------------------------------------------------------------ final Conv2d(funit,3,1) + ZeroPad2d(-2) (UtNet.py:86,88)
 // w: [3][cin] (torch layout), bias [3].  One thread per output pixel; each plane read is a coalesced float4 stream.
-__device__ __forceinline__ void dot3(const f32x4 *__restrict__ s, long np, int planes, const float *__restrict__ w,
-                                     int cin, float &o0, float &o1, float &o2) {
+template <int DT>
+__device__ __forceinline__ void dot3(const typename Elem<DT>::vec *__restrict__ s, long np, int planes,
+                                     const float *__restrict__ w, int cin, float &o0, float &o1, float &o2) {
+    constexpr int N = Elem<DT>::N;
     for (int q = 0; q < planes; ++q) {
-        const f32x4 v = s[(size_t)q * np];
+        const typename Elem<DT>::vec v = s[(size_t)q * np];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int c = 4 * q + e;
+        for (int e = 0; e < N; ++e) {
+            const int c = N * q + e;
             if (c < cin) {
-                o0 = fmaf(v[e], w[c], o0);
-                o1 = fmaf(v[e], w[cin + c], o1);
-                o2 = fmaf(v[e], w[2 * cin + c], o2);
+                const float f = (float)v[e];
+                o0 = fmaf(f, w[c], o0);
+                o1 = fmaf(f, w[cin + c], o1);
+                o2 = fmaf(f, w[2 * cin + c], o2);
             }
         }
     }
 }
 
-__global__ void k_final1x1(const f32x4 *__restrict__ src, long np, int Hb, int Wb, int planes, int cin,
+template <int DT>
+__global__ void k_final1x1(const typename Elem<DT>::vec *__restrict__ src, long np, int Hb, int Wb, int planes, int cin,
                            const float *__restrict__ w, const float *__restrict__ bias, int crop, float *__restrict__ y,
                            int H, int W, int sigmoid) {
     const int xx = blockIdx.x * blockDim.x + threadIdx.x;
     const int yy = blockIdx.y, b = blockIdx.z;
     if (xx >= W) return;
     float o0 = bias[0], o1 = bias[1], o2 = bias[2];
-    dot3(src + ((size_t)b * Hb + yy + crop) * Wb + xx + crop, np, planes, w, cin, o0, o1, o2);
+    dot3<DT>(src + ((size_t)b * Hb + yy + crop) * Wb + xx + crop, np, planes, w, cin, o0, o1, o2);
     if (sigmoid) {   // UNet head (ThirdPartyNets.py:169)
         o0 = 1.f / (1.f + expf(-o0));
         o1 = 1.f / (1.f + expf(-o1));
@@ -372,14 +401,16 @@ int nd_launch_final1x1(const QpBuf &src, int cin, const float *w, const float *b
                        hipStream_t s, int sigmoid) {
     if (src.pad != 0 || src.Hb != H + 2 * crop || src.Wb != W + 2 * crop) ND_FAIL(ND_EINVAL, "final1x1: bad source geometry");
     dim3 grid((W + 255) / 256, H, src.B);
-    hipLaunchKernelGGL(k_final1x1, grid, dim3(256), 0, s, (const f32x4 *)src.base, src.np(), src.Hb, src.Wb,
-                       (cin + 3) / 4, cin, w, bias, crop, y, H, W, sigmoid);
+    const int n = nd_cpp(src.dt);
+    ND_DISPATCH_DT(src.dt, hipLaunchKernelGGL(k_final1x1<DT>, grid, dim3(256), 0, s, (const typename Elem<DT>::vec *)src.base,
+                                              src.np(), src.Hb, src.Wb, (cin + n - 1) / n, cin, w, bias, crop, y, H, W, sigmoid));
     ND_HIP(hipGetLastError());
     return ND_OK;
 }
 
 // fused: final 1x1 + crop + useful crop + seamless edges + canvas += (no NCHW tile batch in HBM)
-__global__ void k_final1x1_stitch(const f32x4 *__restrict__ src, long np, int Hb, int Wb, int planes, int cin,
+template <int DT>
+__global__ void k_final1x1_stitch(const typename Elem<DT>::vec *__restrict__ src, long np, int Hb, int Wb, int planes, int cin,
                                   const float *__restrict__ w, const float *__restrict__ bias, int crop,
                                   float *__restrict__ canvas, TileGeo g, int tile_begin, int tile_count, int y_first) {
     const int X = blockIdx.x * blockDim.x + threadIdx.x;
@@ -391,7 +422,7 @@ __global__ void k_final1x1_stitch(const f32x4 *__restrict__ src, long np, int Hb
     bool any = false;
     for_each_cover(g, X, Y, tile_begin, tile_count, [&](int t, int iy, int ix, float f) {
         float o0 = bias[0], o1 = bias[1], o2 = bias[2];
-        dot3(src + ((size_t)t * Hb + iy + crop) * Wb + ix + crop, np, planes, w, cin, o0, o1, o2);
+        dot3<DT>(src + ((size_t)t * Hb + iy + crop) * Wb + ix + crop, np, planes, w, cin, o0, o1, o2);
         v0 += o0 * f;
         v1 += o1 * f;
         v2 += o2 * f;
@@ -414,8 +445,10 @@ int nd_launch_final1x1_stitch(const QpBuf &src, int cin, const float *w, const f
     stitch_band(g, tile_begin, tile_count, &yf, &yr);
     if (yr <= 0) return ND_OK;
     dim3 grid((W + 255) / 256, yr);
-    hipLaunchKernelGGL(k_final1x1_stitch, grid, dim3(256), 0, s, (const f32x4 *)src.base, src.np(), src.Hb, src.Wb,
-                       (cin + 3) / 4, cin, w, bias, crop, canvas, g, tile_begin, tile_count, yf);
+    const int n = nd_cpp(src.dt);
+    ND_DISPATCH_DT(src.dt, hipLaunchKernelGGL(k_final1x1_stitch<DT>, grid, dim3(256), 0, s, (const typename Elem<DT>::vec *)src.base,
+                                              src.np(), src.Hb, src.Wb, (cin + n - 1) / n, cin, w, bias, crop, canvas, g,
+                                              tile_begin, tile_count, yf));
     ND_HIP(hipGetLastError());
     return ND_OK;
 }

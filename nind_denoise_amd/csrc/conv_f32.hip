@@ -39,6 +39,18 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// One 16-byte MFMA operand fragment per lane and K block:
+//   ND_F32  : 4 fp32 channels  -> 4 x v_mfma_f32_32x32x2_f32   (K block = 8 channels over the two lane halves)
+//   ND_BF16 : 8 bf16 channels  -> 1 x v_mfma_f32_32x32x16_bf16 (K block = 16 channels)
+//   ND_F16  : 8 fp16 channels  -> 1 x v_mfma_f32_32x32x16_f16
+template <int DT> struct FragOf { typedef f32x4 type; };
+template <> struct FragOf<ND_BF16> { typedef bf16x8 type; };
+template <> struct FragOf<ND_F16> { typedef f16x8 type; };
 
 struct ConvParams {
     const f32x4 *in;     // plane 0 of the input buffer
@@ -89,8 +101,9 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 }
 
 // MR x NR : 32x32 MFMA tiles per wave;  WM x WN : waves per workgroup;  TAPS in {9,1};  KBC : 8-channel blocks per chunk
-template <int MR, int NR, int WM, int WN, int TAPS, int KBC, bool UP, int NSTAGE>
-__global__ __launch_bounds__(64 * WM * WN) void conv_qp_f32(ConvParams p) {
+template <int DT, int MR, int NR, int WM, int WN, int TAPS, int KBC, bool UP, int NSTAGE>
+__global__ __launch_bounds__(64 * WM * WN) void conv_qp(ConvParams p) {
+    typedef typename FragOf<DT>::type Frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = WM * WN;
     constexpr int MTB = MR * WM;                    // 32-row tiles per workgroup
@@ -210,16 +223,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_qp_f32(ConvParams p) {
         return o;
     };
     BOff bOff = lane_offsets(vb), bOffN = bOff;
-    f32x4 a[2][MR] = {}, b[2][NR] = {};
+    Frag a[2][MR] = {}, b[2][NR] = {};
     auto load_frags = [&](int buf, const char *sb, int step, const BOff &bo) {
         if (p.ablate & 8) return;
         const int kbl = step / TAPS, t = step % TAPS;
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr)
-            a[buf][mr] = *(const f32x4 *)(sb + aOff + ((mr * KBC + kbl) * TAPS + t) * 1024);
+            a[buf][mr] = *(const Frag *)(sb + aOff + ((mr * KBC + kbl) * TAPS + t) * 1024);
 #pragma unroll
         for (int nr = 0; nr < NR; ++nr)
-            b[buf][nr] = *(const f32x4 *)(sb + bo.v[nr] + kbl * 2 * planeB + toff[t]);
+            b[buf][nr] = *(const Frag *)(sb + bo.v[nr] + kbl * 2 * planeB + toff[t]);
     };
 
     f32x16 acc[MR][NR];
@@ -265,15 +278,33 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_qp_f32(ConvParams p) {
                             else
                                 v[e] = t > 0.f ? t : t * slope;  // PReLU; "no activation" is slope 1
                         }
-                        long off;
+                        // destination channel (a multiple of 4) and pixel
+                        int co = m4;
+                        long pix = pbase;
                         if (UP) {
                             const int ab = m4 / p.cout;
-                            const int co = m4 - ab * p.cout;
-                            off = (long)(p.out_plane0 + (co >> 2)) * p.out_plane + pbase + (long)(ab >> 1) * p.Wo + (ab & 1);
-                        } else {
-                            off = (long)(p.out_plane0 + (m4 >> 2)) * p.out_plane + pbase;
+                            co = m4 - ab * p.cout;
+                            pix += (long)(ab >> 1) * p.Wo + (ab & 1);
                         }
-                        if (!(p.ablate & 4)) p.out[off] = v;
+                        if (!(p.ablate & 4)) {
+                            if constexpr (DT == ND_F32) {
+                                p.out[(long)(p.out_plane0 + (co >> 2)) * p.out_plane + pix] = v;
+                            } else {
+                                // a 16-bit plane element holds 8 channels: this lane owns its lower or upper half (8 bytes)
+                                char *dst = (char *)p.out + (((long)(p.out_plane0 + (co >> 3)) * p.out_plane + pix) << 4) + ((co >> 2) & 1) * 8;
+                                if constexpr (DT == ND_BF16) {
+                                    bf16x4 o;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+                                    *(bf16x4 *)dst = o;
+                                } else {
+                                    f16x4 o;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
+                                    *(f16x4 *)dst = o;
+                                }
+                            }
+                        }
                     }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[mr][nr][4 * g + e] = 0.f;
@@ -307,13 +338,25 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_qp_f32(ConvParams p) {
                 load_frags((st + 1) & 1, sb, st + 1, bOff);
             else if (NSTAGE == 3 && s + 1 < nsteps)   // next step's first fragments, before its barrier
                 load_frags((st + 1) & 1, smem + n_stage * stageB, 0, last_chunk ? bOffN : bOff);
+            if constexpr (DT == ND_F32) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                        for (int nr = 0; nr < NR; ++nr)
+                            acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st & 1][mr][q], b[st & 1][nr][q], acc[mr][nr], 0, 0, 0);
+            } else {
 #pragma unroll
                 for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
-                    for (int nr = 0; nr < NR; ++nr)
-                        acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st & 1][mr][q], b[st & 1][nr][q], acc[mr][nr], 0, 0, 0);
+                    for (int nr = 0; nr < NR; ++nr) {
+                        if constexpr (DT == ND_BF16)
+                            acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[st & 1][mr], b[st & 1][nr], acc[mr][nr], 0, 0, 0);
+                        else
+                            acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[st & 1][mr], b[st & 1][nr], acc[mr][nr], 0, 0, 0);
+                    }
+            }
         }
         if (NSTAGE == 3 && (STEPS & 1)) {
             // an odd number of sub-steps leaves the prefetched fragments in buffer 1: the next step starts from buffer 0
@@ -338,31 +381,37 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_qp_f32(ConvParams p) {
 // ------------------------------------------------------------------ variants and dispatch
 struct Variant {
     const char *name;
-    int mblk, nblk, threads, taps, kbc, nstage;
+    int dt, mblk, nblk, threads, taps, kbc, nstage;
     bool up;
     void (*fn)(ConvParams);
 };
 
-#define ND_VARIANT(MR, NR, WM, WN, TAPS, KBC, UP, NS)                                                               \
-    {                                                                                                               \
-        "f32_m" #MR "x" #WM "_n" #NR "x" #WN "_t" #TAPS "_k" #KBC "_up" #UP "_s" #NS, 32 * MR * WM, 32 * NR * WN,   \
-            64 * WM * WN, TAPS, KBC, NS, UP, conv_qp_f32<MR, NR, WM, WN, TAPS, KBC, UP, NS>                         \
+#define ND_VARIANT(DT, DTN, MR, NR, WM, WN, TAPS, KBC, UP, NS)                                                         \
+    {                                                                                                                  \
+        DTN "_m" #MR "x" #WM "_n" #NR "x" #WN "_t" #TAPS "_k" #KBC "_up" #UP "_s" #NS, DT, 32 * MR * WM, 32 * NR * WN,  \
+            64 * WM * WN, TAPS, KBC, NS, UP, conv_qp<DT, MR, NR, WM, WN, TAPS, KBC, UP, NS>                            \
     }
+// the shapes every storage type gets (index inside a dtype group)
+#define ND_VARIANT_GROUP(DT, DTN)                                                                                      \
+    ND_VARIANT(DT, DTN, 2, 2, 1, 8, 9, 1, false, 3),  /* 0: M64  x N512, 8 waves, 3 stages  (default 3x3)           */ \
+    ND_VARIANT(DT, DTN, 2, 2, 1, 8, 9, 1, false, 2),  /* 1: M64  x N512, 8 waves, 2 stages  (wide rows: cs >= ~400) */ \
+    ND_VARIANT(DT, DTN, 2, 2, 1, 4, 9, 1, false, 2),  /* 2: M64  x N256, 4 waves, 2 stages  (widest rows)           */ \
+    ND_VARIANT(DT, DTN, 1, 2, 1, 8, 9, 1, false, 3),  /* 3: M32  x N512, 8 waves (narrow nets / tests)              */ \
+    ND_VARIANT(DT, DTN, 2, 2, 1, 8, 1, 2, false, 3),  /* 4: 1x1, M64 x N512                                         */ \
+    ND_VARIANT(DT, DTN, 2, 2, 1, 8, 1, 1, false, 3),  /* 5: 1x1, single-K-block chunks                              */ \
+    ND_VARIANT(DT, DTN, 2, 2, 1, 8, 1, 2, true, 3),   /* 6: up (2x2 s2), M64 x N512                                 */ \
+    ND_VARIANT(DT, DTN, 2, 2, 1, 8, 1, 1, true, 3),   /* 7: up, single-K-block chunks                               */ \
+    ND_VARIANT(DT, DTN, 4, 2, 2, 4, 1, 2, true, 3)    /* 8: up, M256 x N256, 8 waves x (128x64)                     */
+constexpr int kGroup = 9;
 
 static const Variant g_variants[] = {
-    ND_VARIANT(2, 2, 1, 8, 9, 1, false, 3),  // 0: M64  x N512, 8 waves, 3 stages  (default 3x3)
-    ND_VARIANT(2, 2, 1, 8, 9, 1, false, 2),  // 1: M64  x N512, 8 waves, 2 stages  (wide rows: cs >= ~400)
-    ND_VARIANT(2, 2, 1, 4, 9, 1, false, 2),  // 2: M64  x N256, 4 waves, 2 stages  (widest rows)
-    ND_VARIANT(2, 2, 2, 4, 9, 1, false, 3),  // 3: M128 x N256, 8 waves, 3 stages
-    ND_VARIANT(1, 2, 1, 8, 9, 1, false, 3),  // 4: M32  x N512, 8 waves (narrow nets / tests)
-    ND_VARIANT(2, 2, 1, 4, 9, 1, false, 3),  // 5: M64  x N256, 4 waves, 3 stages
-    ND_VARIANT(2, 2, 1, 8, 1, 2, false, 3),  // 6: 1x1, M64 x N512
-    ND_VARIANT(2, 2, 1, 8, 1, 1, false, 3),  // 7: 1x1, K chunk of 8 channels (Cin == 8 mod 16)
-    ND_VARIANT(2, 2, 1, 8, 1, 2, true, 3),   // 8: up (2x2 s2), M64 x N512
-    ND_VARIANT(2, 2, 2, 4, 1, 2, true, 3),   // 9: up, M128 x N256
-    ND_VARIANT(2, 2, 1, 8, 1, 1, true, 3),   // 10: up, K chunk of 8 channels
-    ND_VARIANT(2, 2, 2, 2, 1, 2, true, 2),   // 11: up, M128 x N128, 4 waves, 2 stages
-    ND_VARIANT(4, 2, 2, 4, 1, 2, true, 3),   // 12: up, M256 x N256, 8 waves x (128x64): activations re-read M/256 times only
+    ND_VARIANT_GROUP(ND_F32, "f32"),
+    ND_VARIANT_GROUP(ND_BF16, "bf16"),
+    ND_VARIANT_GROUP(ND_F16, "f16"),
+    // fp32-only experiments
+    ND_VARIANT(ND_F32, "f32", 2, 2, 2, 4, 9, 1, false, 3),  // M128 x N256, 8 waves, 3 stages
+    ND_VARIANT(ND_F32, "f32", 2, 2, 1, 4, 9, 1, false, 3),  // M64  x N256, 4 waves, 3 stages
+    ND_VARIANT(ND_F32, "f32", 2, 2, 2, 4, 1, 2, true, 3),   // up, M128 x N256
 };
 static const int g_nvariants = (int)(sizeof(g_variants) / sizeof(g_variants[0]));
 
@@ -401,28 +450,31 @@ static const size_t kMaxLds = 160 * 1024;
 static int pick_variant(const ConvDesc &d, int M) {
     const int taps = nd_taps(d.kind);
     const bool up = d.kind == ND_CONVT2S2;
-    const int KB = nd_kblocks(d.cin);
+    const int dt = d.in.dt;
+    const int KB = nd_kblocks(d.cin, dt);
+    const int g0 = dt * kGroup;
     if (taps == 9) {
-        const int first = M <= 32 ? 4 : 0;
-        const int order[] = {first, 0, 1, 2};
+        const int order[] = {M <= 32 ? 3 : 0, 0, 1, 2};
         for (int v : order)
-            if (variant_lds(g_variants[v], d.in) <= kMaxLds) return v;
-        return 2;
+            if (variant_lds(g_variants[g0 + v], d.in) <= kMaxLds) return g0 + v;
+        return g0 + 2;
     }
-    if (KB % 2) return up ? 10 : 7;
-    if (up) return M >= 256 ? 12 : 8;
-    return 6;
+    if (KB % 2) return g0 + (up ? 7 : 5);
+    if (up) return g0 + (M >= 256 ? 8 : 6);
+    return g0 + 4;
 }
 
 static int g_num_cus = 0;
 static int g_lds_set[64] = {0};
 
-int nd_launch_conv_f32(const ConvDesc &d, hipStream_t stream) {
+int nd_launch_conv(const ConvDesc &d, hipStream_t stream) {
     const int taps = nd_taps(d.kind);
     const bool up = d.kind == ND_CONVT2S2;
-    const int KB = nd_kblocks(d.cin);
+    const int dt = d.in.dt;
+    if (dt < ND_F32 || dt > ND_F16 || d.out.dt != dt) ND_FAIL(ND_EINVAL, "conv: input / output storage types %d / %d", d.in.dt, d.out.dt);
+    const int KB = nd_kblocks(d.cin, dt);
     const int M = up ? 4 * d.cout : d.cout;
-    if (d.cout % 4) ND_FAIL(ND_EINVAL, "conv: cout=%d must be a multiple of 4", d.cout);
+    if (d.cout % nd_cpp(dt)) ND_FAIL(ND_EINVAL, "conv: cout=%d must be a multiple of %d", d.cout, nd_cpp(dt));
     if (d.in.planes < 2 * KB) ND_FAIL(ND_EINVAL, "conv: input buffer has %d planes, needs %d", d.in.planes, 2 * KB);
     const long NP = d.in.used();
     if (NP >= (1L << 31)) ND_FAIL(ND_EINVAL, "conv: %ld linear pixels exceed the int32 index range", NP);
@@ -430,7 +482,7 @@ int nd_launch_conv_f32(const ConvDesc &d, hipStream_t stream) {
     int v = d.variant >= 0 ? d.variant : pick_variant(d, M);
     if (v < 0 || v >= g_nvariants) ND_FAIL(ND_EINVAL, "conv: unknown variant %d", v);
     const Variant &V = g_variants[v];
-    if (V.taps != taps || V.up != up) ND_FAIL(ND_EINVAL, "conv: variant %s does not match layer kind %d", V.name, d.kind);
+    if (V.taps != taps || V.up != up || V.dt != dt) ND_FAIL(ND_EINVAL, "conv: variant %s does not match layer kind %d / dtype %d", V.name, d.kind, dt);
     if (KB % V.kbc) ND_FAIL(ND_EINVAL, "conv: Cin/8=%d not a multiple of the variant's K chunk %d", KB, V.kbc);
 
     ConvParams p;
@@ -468,7 +520,7 @@ int nd_launch_conv_f32(const ConvDesc &d, hipStream_t stream) {
     if (!fits || d.out.B != d.in.B)
         ND_FAIL(ND_EINVAL, "conv: destination %dx%dx%d(pad %d) does not fit result %dx%dx%d", d.out.B, d.out.Hb, d.out.Wb,
                 d.out.pad, d.in.B, oh, ow);
-    if (d.out_plane0 + d.cout / 4 > d.out.planes) ND_FAIL(ND_EINVAL, "conv: destination planes overflow");
+    if (d.out_plane0 + d.cout / nd_cpp(dt) > d.out.planes) ND_FAIL(ND_EINVAL, "conv: destination planes overflow");
 
     bool cross = true;
     const size_t lds = variant_lds(V, d.in, &cross, &p.G);

@@ -33,12 +33,16 @@ void nd_set_error(const char *fmt, ...);
 // Within a plane all images are contiguous, so a pixel has ONE linear index p = (b*Hb + y)*Wb + x and the 3x3
 // neighbour (ky,kx) is p + ky*Wb + kx: an implicit-GEMM N tile is a contiguous pixel range and its LDS halo
 // image is a contiguous copy.
+// A plane element is ALWAYS 16 bytes per pixel: 4 fp32 channels (ND_F32) or 8 bf16 / fp16 channels (ND_BF16 / ND_F16),
+// so the pixel indexing, the LDS-DMA images and the ds_read_b128 fragment reads are identical for every storage type.
+static inline int nd_cpp(int dt) { return dt == ND_F32 ? 4 : 8; }   // channels per plane
 struct QpBuf {
     float *base;    // first plane
-    int planes;     // C/4 (channels padded to a multiple of 4)
+    int planes;     // C / nd_cpp(dt) (channels padded to a whole plane)
     int B, Hb, Wb;  // images in use, bordered rows / cols
     int pad;        // zero border width
-    long pstride;   // float4 per plane (capacity: batch * Hb * Wb); B may be smaller for a partial batch
+    long pstride;   // 16-byte elements per plane (capacity: batch * Hb * Wb); B may be smaller for a partial batch
+    int dt = ND_F32;  // storage type (nd_dtype)
     long np() const { return pstride; }
     long used() const { return (long)B * Hb * Wb; }
 };
@@ -57,7 +61,8 @@ struct ConvDesc {
     int out_plane0;     // first destination plane (channel offset / 4) inside `out`
     int variant;        // -1: pick automatically
 };
-int nd_launch_conv_f32(const ConvDesc &d, hipStream_t stream);
+int nd_launch_conv(const ConvDesc &d, hipStream_t stream);
+static inline int nd_launch_conv_f32(const ConvDesc &d, hipStream_t stream) { return nd_launch_conv(d, stream); }
 int nd_conv_variant_count();
 const char *nd_conv_variant_label(int v);
 
@@ -67,11 +72,16 @@ static inline int nd_mtiles(int kind, int cout) {
     return kind == ND_CONVT2S2 ? (4 * cout + 255) / 256 * 8 : (cout + 127) / 128 * 4;   // up layers use 256-row workgroup tiles
 }
 static inline int nd_taps(int kind) { return (kind == ND_CONV3 || kind == ND_CONVT3) ? 9 : 1; }
-static inline int nd_kblocks(int cin) { return (cin + 7) / 8; }
-static inline size_t nd_packed_floats(int kind, int cin, int cout) {
-    return (size_t)nd_mtiles(kind, cout) * nd_kblocks(cin) * nd_taps(kind) * 256 + (size_t)nd_mtiles(kind, cout) * 32;
+// K block = two planes = the K extent of one ds_read_b128 per operand: 8 fp32 channels or 16 bf16/fp16 channels
+static inline int nd_kblocks(int cin, int dt = ND_F32) { return (cin + 2 * nd_cpp(dt) - 1) / (2 * nd_cpp(dt)); }
+// packed layer size in 4-byte units: 1 KiB fragment pieces [mtile][kb][tap] (any dtype) + fp32 bias[mtiles*32]
+static inline size_t nd_packed_floats(int kind, int cin, int cout, int dt = ND_F32) {
+    return (size_t)nd_mtiles(kind, cout) * nd_kblocks(cin, dt) * nd_taps(kind) * 256 + (size_t)nd_mtiles(kind, cout) * 32;
 }
-void nd_pack_layer_f32(int kind, int cin, int cout, const float *w, const float *bias, float *packed);
+void nd_pack_layer(int kind, int cin, int cout, int dt, const float *w, const float *bias, float *packed);
+static inline void nd_pack_layer_f32(int kind, int cin, int cout, const float *w, const float *bias, float *packed) {
+    nd_pack_layer(kind, cin, cout, ND_F32, w, bias, packed);
+}
 
 // ------------------------------------------------------------------ auxiliary kernels (aux_kernels.hip)
 int nd_launch_nchw_to_qp(const float *x, int C, const QpBuf &dst, int plane0, hipStream_t s);

@@ -75,7 +75,7 @@ struct BlobLayout {
     size_t off[kNumLayers];
     size_t total;
 };
-BlobLayout blob_layout(int f) {
+BlobLayout blob_layout(int f, int dt) {
     BlobLayout b;
     size_t o = kHeaderFloats;
     for (int i = 0; i < kNumLayers; ++i) {
@@ -84,7 +84,7 @@ BlobLayout blob_layout(int f) {
         if (i == kNumLayers - 1)
             o += ((size_t)3 * lcin(l, f) + 3 + 3) / 4 * 4;  // raw [3][cin] + bias[3] for the VALU 1x1 kernel
         else
-            o += nd_packed_floats(l.kind, lcin(l, f), lcout(l, f));
+            o += nd_packed_floats(l.kind, lcin(l, f), lcout(l, f), dt);
     }
     b.total = o;
     return b;
@@ -92,9 +92,15 @@ BlobLayout blob_layout(int f) {
 
 bool valid_cs(int cs) { return cs >= 104 && (cs - 56) % 16 == 0; }
 
+int check_funit(int funit, int dtype) {
+    if (dtype < ND_F32 || dtype > ND_F16) ND_FAIL(ND_EINVAL, "UtNet: unsupported dtype %d", dtype);
+    const int q = 2 * nd_cpp(dtype);   // every conv input must be whole K blocks: 8 (fp32) / 16 (bf16, fp16) channels
+    if (funit < q || funit % q) ND_FAIL(ND_EINVAL, "UtNet: funit=%d must be a positive multiple of %d for dtype %d", funit, q, dtype);
+    return ND_OK;
+}
+
 int check_net(int funit, int h, int w, int batch, int dtype) {
-    if (dtype != ND_F32) ND_FAIL(ND_EINVAL, "UtNet: unsupported dtype %d", dtype);
-    if (funit < 8 || funit % 8) ND_FAIL(ND_EINVAL, "UtNet: funit=%d must be a positive multiple of 8", funit);
+    ND_TRY(check_funit(funit, dtype));
     for (int cs : {h, w})
         if (!valid_cs(cs))
             ND_FAIL(ND_EINVAL, "UtNet: tile size %d is not of the form 16k+56 (104, 120, ..., 248, 264, ..., 504, 520); "
@@ -112,7 +118,7 @@ struct Plan {
 };
 
 // cap = batch the workspace was sized for; nimg = images in use (<= cap)
-Plan make_plan(int f, int ch_, int cw_, int cap, int nimg, char *base) {
+Plan make_plan(int f, int ch_, int cw_, int cap, int nimg, char *base, int dt) {
     Plan p;
     size_t off = 0;
     // `size` is the extent of the tensor for a SQUARE cs x cs input; the other dimension follows the same chain
@@ -124,8 +130,9 @@ Plan make_plan(int f, int ch_, int cw_, int cap, int nimg, char *base) {
     };
     auto add = [&](Buf id, int ch, int /*size*/, int pad) {
         QpBuf &q = p.buf[id];
-        q.planes = (ch + 3) / 4;
-        if (id == X0) q.planes = 2;
+        q.planes = (ch + nd_cpp(dt) - 1) / nd_cpp(dt);
+        if (id == X0) q.planes = 2;   // one K block: plane 0 = (r,g,b,0..), plane 1 = zeros
+        q.dt = dt;
         q.B = nimg;
         q.Hb = chain(ch_, (int)id) + 2 * pad;
         q.Wb = chain(cw_, (int)id) + 2 * pad;
@@ -182,15 +189,16 @@ const Step kSteps[kNumSteps] = {
 };
 
 // ev (optional): kNumSteps+1 events, ev[i] recorded before step i, ev[kNumSteps] after the last one
-int run_stack(int f, int act, const float *blob, const Plan &pl, hipStream_t s, hipEvent_t *ev = nullptr) {
-    const BlobLayout bl = blob_layout(f);
+int run_stack(int f, int act, int dt, const float *blob, const Plan &pl, hipStream_t s, hipEvent_t *ev = nullptr) {
+    const BlobLayout bl = blob_layout(f, dt);
+    const int cpp = nd_cpp(dt);
     int si = 0;
     for (const Step &st : kSteps) {
         if (ev) ND_HIP(hipEventRecord(ev[si], s));
         ++si;
         if (st.layer < 0) {
             // pool reads the skip half of the concat buffer: planes [mul*f/4, 2*mul*f/4)
-            ND_TRY(nd_launch_maxpool2(pl.buf[st.src], st.dst_plane0_mul * f / 4, st.dst_plane0_mul * f / 4, pl.buf[st.dst], s));
+            ND_TRY(nd_launch_maxpool2(pl.buf[st.src], st.dst_plane0_mul * f / cpp, st.dst_plane0_mul * f / cpp, pl.buf[st.dst], s));
             continue;
         }
         const LayerSpec &l = kLayers[st.layer];
@@ -202,12 +210,12 @@ int run_stack(int f, int act, const float *blob, const Plan &pl, hipStream_t s, 
         d.cin = lcin(l, f);
         d.cout = lcout(l, f);
         d.wpk = blob + bl.off[st.layer];
-        d.bias = d.wpk + (size_t)nd_mtiles(l.kind, d.cout) * nd_kblocks(d.cin) * nd_taps(l.kind) * 256;
+        d.bias = d.wpk + (size_t)nd_mtiles(l.kind, d.cout) * nd_kblocks(d.cin, dt) * nd_taps(l.kind) * 256;
         d.in = pl.buf[st.src];
         d.out = pl.buf[st.dst];
-        d.out_plane0 = st.dst_plane0_mul * f / 4;
+        d.out_plane0 = st.dst_plane0_mul * f / cpp;
         d.variant = -1;
-        ND_TRY(nd_launch_conv_f32(d, s));
+        ND_TRY(nd_launch_conv(d, s));
     }
     if (ev) ND_HIP(hipEventRecord(ev[si], s));
     return ND_OK;
@@ -223,16 +231,15 @@ extern "C" const char *nd_utnet_tensor_name(int idx) {
 }
 
 extern "C" size_t nd_utnet_packed_bytes(int funit, int dtype) {
-    if (dtype != ND_F32 || funit < 8 || funit % 8) return 0;
-    return blob_layout(funit).total * sizeof(float);
+    if (check_funit(funit, dtype) != ND_OK) return 0;
+    return blob_layout(funit, dtype).total * sizeof(float);
 }
 
 extern "C" int nd_utnet_pack_weights(int funit, int dtype, const float *const *tensors, int n_tensors, void *packed_host,
                                      size_t packed_bytes) {
-    if (dtype != ND_F32) ND_FAIL(ND_EINVAL, "nd_utnet_pack_weights: unsupported dtype %d", dtype);
-    if (funit < 8 || funit % 8) ND_FAIL(ND_EINVAL, "nd_utnet_pack_weights: funit=%d must be a positive multiple of 8", funit);
+    ND_TRY(check_funit(funit, dtype));
     if (n_tensors != nd_utnet_num_tensors()) ND_FAIL(ND_EINVAL, "nd_utnet_pack_weights: expected %d tensors, got %d", nd_utnet_num_tensors(), n_tensors);
-    const BlobLayout bl = blob_layout(funit);
+    const BlobLayout bl = blob_layout(funit, dtype);
     if (packed_bytes < bl.total * sizeof(float)) ND_FAIL(ND_ENOMEM, "nd_utnet_pack_weights: packed buffer too small");
     float *blob = (float *)packed_host;
     memset(blob, 0, bl.total * sizeof(float));
@@ -245,7 +252,7 @@ extern "C" int nd_utnet_pack_weights(int funit, int dtype, const float *const *t
             memcpy(blob + bl.off[i], tensors[wi], sizeof(float) * 3 * ci);
             memcpy(blob + bl.off[i] + 3 * ci, tensors[bi], sizeof(float) * 3);
         } else {
-            nd_pack_layer_f32(l.kind, ci, co, tensors[wi], tensors[bi], blob + bl.off[i]);
+            nd_pack_layer(l.kind, ci, co, dtype, tensors[wi], tensors[bi], blob + bl.off[i]);
         }
         if (l.prelu >= 0) {
             // activation module sits right after the layer in its Sequential: "<seq>.<k+1>.weight"
@@ -261,7 +268,7 @@ extern "C" int nd_utnet_pack_weights(int funit, int dtype, const float *const *t
 
 extern "C" size_t nd_utnet_workspace_bytes_hw(int funit, int h, int w, int batch, int dtype) {
     if (check_net(funit, h, w, batch, dtype) != ND_OK) return 0;
-    return make_plan(funit, h, w, batch, batch, nullptr).bytes;
+    return make_plan(funit, h, w, batch, batch, nullptr, dtype).bytes;
 }
 extern "C" size_t nd_utnet_workspace_bytes(int funit, int cs, int batch, int dtype) {
     return nd_utnet_workspace_bytes_hw(funit, cs, cs, batch, dtype);
@@ -275,7 +282,7 @@ extern "C" int nd_utnet_workspace_init(void *ws, size_t ws_bytes, int funit, int
 extern "C" int nd_utnet_workspace_init_hw(void *ws, size_t ws_bytes, int funit, int h, int w, int batch, int dtype,
                                           void *stream) {
     ND_TRY(check_net(funit, h, w, batch, dtype));
-    const size_t need = make_plan(funit, h, w, batch, batch, nullptr).bytes;
+    const size_t need = make_plan(funit, h, w, batch, batch, nullptr, dtype).bytes;
     if (!ws || ws_bytes < need) ND_FAIL(ND_ENOMEM, "UtNet workspace: %zu B given, %zu B needed", ws_bytes, need);
     // zero borders (the implicit padding of the transpose convolutions), the unused input channel plane and the slack
     ND_HIP(hipMemsetAsync(ws, 0, need, (hipStream_t)stream));
@@ -289,7 +296,7 @@ static int forward_common(int funit, int act, int dtype, const void *packed, int
     if (nimg <= 0 || nimg > batch_cap) ND_FAIL(ND_EINVAL, "UtNet: %d images with a workspace batch of %d", nimg, batch_cap);
     if (!packed || !ws) ND_FAIL(ND_EINVAL, "UtNet: null pointer");
     if (((uintptr_t)ws & 15) || ((uintptr_t)packed & 15)) ND_FAIL(ND_EINVAL, "UtNet: workspace / weights must be 16-byte aligned");
-    *out_plan = make_plan(funit, h, w, batch_cap, nimg, (char *)ws);
+    *out_plan = make_plan(funit, h, w, batch_cap, nimg, (char *)ws, dtype);
     if (ws_bytes < out_plan->bytes) ND_FAIL(ND_ENOMEM, "UtNet workspace: %zu B given, %zu B needed", ws_bytes, out_plan->bytes);
     return ND_OK;
 }
@@ -308,8 +315,8 @@ extern "C" int nd_utnet_forward_hw(int funit, int act, int dtype, const void *pa
     hipStream_t s = (hipStream_t)stream;
     const float *blob = (const float *)packed;
     ND_TRY(nd_launch_reflect_pack(x, batch, h, w, pl.buf[X0], s));
-    ND_TRY(run_stack(funit, act, blob, pl, s));
-    const BlobLayout bl = blob_layout(funit);
+    ND_TRY(run_stack(funit, act, dtype, blob, pl, s));
+    const BlobLayout bl = blob_layout(funit, dtype);
     const float *fw = blob + bl.off[kNumLayers - 1];
     ND_TRY(nd_launch_final1x1(pl.buf[T4B], funit, fw, fw + 3 * funit, 2, y, h, w, s));
     return ND_OK;
@@ -324,8 +331,8 @@ extern "C" int nd_utnet_denoise_tiles(int funit, int act, int dtype, const void 
     hipStream_t s = (hipStream_t)stream;
     const float *blob = (const float *)packed;
     ND_TRY(nd_launch_gather_pack(img, width, height, cs, ucs, ol, tile_begin, tile_count, pl.buf[X0], s));
-    ND_TRY(run_stack(funit, act, blob, pl, s));
-    const BlobLayout bl = blob_layout(funit);
+    ND_TRY(run_stack(funit, act, dtype, blob, pl, s));
+    const BlobLayout bl = blob_layout(funit, dtype);
     const float *fw = blob + bl.off[kNumLayers - 1];
     ND_TRY(nd_launch_final1x1_stitch(pl.buf[T4B], funit, fw, fw + 3 * funit, 2, canvas, width, height, cs, ucs, ol,
                                      tile_begin, tile_count, s));
@@ -344,7 +351,7 @@ extern "C" int nd_utnet_profile_stack(int funit, int act, int dtype, const void 
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t ev[kNumSteps + 1];
     for (auto &e : ev) ND_HIP(hipEventCreate(&e));
-    int rc = run_stack(funit, act, (const float *)packed, pl, s, ev);
+    int rc = run_stack(funit, act, dtype, (const float *)packed, pl, s, ev);
     if (rc == ND_OK) {
         hipError_t e = hipStreamSynchronize(s);
         if (e != hipSuccess) {
@@ -416,10 +423,11 @@ struct LayerPlan {
     QpBuf in, out;
     size_t bytes;
 };
-LayerPlan layer_plan(int kind, int B, int cin, int cout, int h, int w, char *base) {
+LayerPlan layer_plan(int kind, int B, int cin, int cout, int h, int w, char *base, int dt = ND_F32) {
     LayerPlan p;
     const int ipad = kind == ND_CONVT3 ? 2 : 0;
-    p.in.planes = 2 * nd_kblocks(cin);
+    p.in.dt = p.out.dt = dt;
+    p.in.planes = 2 * nd_kblocks(cin, dt);
     p.in.B = B;
     p.in.Hb = h + 2 * ipad;
     p.in.Wb = w + 2 * ipad;
@@ -435,7 +443,7 @@ LayerPlan layer_plan(int kind, int B, int cin, int cout, int h, int w, char *bas
         case ND_CONVT2S2: oh = 2 * h; ow = 2 * w; break;
         default: oh = h; ow = w; break;
     }
-    p.out.planes = (cout + 3) / 4;
+    p.out.planes = (cout + nd_cpp(dt) - 1) / nd_cpp(dt);
     p.out.B = B;
     p.out.Hb = oh;
     p.out.Wb = ow;
@@ -449,21 +457,21 @@ LayerPlan layer_plan(int kind, int B, int cin, int cout, int h, int w, char *bas
 }  // namespace
 
 extern "C" size_t nd_layer_workspace_bytes(int kind, int batch, int cin, int cout, int h, int w, int dtype) {
-    if (dtype != ND_F32 || kind < 0 || kind > 3 || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return 0;
+    if (dtype < ND_F32 || dtype > ND_F16 || kind < 0 || kind > 3 || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return 0;
     if (kind == ND_CONV3 && (h < 3 || w < 3)) return 0;
-    return layer_plan(kind, batch, cin, cout, h, w, nullptr).bytes;
+    return layer_plan(kind, batch, cin, cout, h, w, nullptr, dtype).bytes;
 }
 
 extern "C" int nd_layer_forward(int kind, int act, float slope, int dtype, const void *packed, const float *x, int batch,
                                 int cin, int h, int w, int cout, float *y, void *ws, size_t ws_bytes, int variant,
                                 void *stream) {
-    if (dtype != ND_F32) ND_FAIL(ND_EINVAL, "nd_layer_forward: unsupported dtype %d", dtype);
+    if (dtype < ND_F32 || dtype > ND_F16) ND_FAIL(ND_EINVAL, "nd_layer_forward: unsupported dtype %d", dtype);
     const size_t need = nd_layer_workspace_bytes(kind, batch, cin, cout, h, w, dtype);
     if (!need) ND_FAIL(ND_EINVAL, "nd_layer_forward: bad shape");
     if (!ws || ws_bytes < need) ND_FAIL(ND_ENOMEM, "nd_layer_forward: workspace %zu B given, %zu B needed", ws_bytes, need);
-    if (cout % 4) ND_FAIL(ND_EINVAL, "nd_layer_forward: cout must be a multiple of 4");
+    if (cout % nd_cpp(dtype)) ND_FAIL(ND_EINVAL, "nd_layer_forward: cout must be a multiple of %d", nd_cpp(dtype));
     hipStream_t s = (hipStream_t)stream;
-    LayerPlan pl = layer_plan(kind, batch, cin, cout, h, w, (char *)ws);
+    LayerPlan pl = layer_plan(kind, batch, cin, cout, h, w, (char *)ws, dtype);
     ND_HIP(hipMemsetAsync(ws, 0, need, s));
     ND_TRY(nd_launch_nchw_to_qp(x, cin, pl.in, 0, s));
     ConvDesc d;
@@ -474,12 +482,12 @@ extern "C" int nd_layer_forward(int kind, int act, float slope, int dtype, const
     d.cin = cin;
     d.cout = cout;
     d.wpk = (const float *)packed;
-    d.bias = d.wpk + (size_t)nd_mtiles(kind, cout) * nd_kblocks(cin) * nd_taps(kind) * 256;
+    d.bias = d.wpk + (size_t)nd_mtiles(kind, cout) * nd_kblocks(cin, dtype) * nd_taps(kind) * 256;
     d.in = pl.in;
     d.out = pl.out;
     d.out_plane0 = 0;
     d.variant = variant;
-    ND_TRY(nd_launch_conv_f32(d, s));
+    ND_TRY(nd_launch_conv(d, s));
     ND_TRY(nd_launch_qp_to_nchw(pl.out, 0, y, cout, s));
     return ND_OK;
 }
@@ -516,18 +524,43 @@ __global__ void k_fill_random(float *p, size_t n, unsigned seed) {
     }
 }
 
-extern "C" int nd_conv_bench(int kind, int batch, int cin, int cout, int h, int w, int variant, int iters, void *ws,
+__global__ void k_fill_random16(unsigned short *p, size_t n, unsigned seed, int dt) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        unsigned h = (unsigned)i * 2654435761u ^ seed;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        const float f = ((h & 0xFFFF) - 32768.f) * (1.f / 65536.f);
+        if (dt == ND_BF16) {
+            const __bf16 v = (__bf16)f;
+            p[i] = *(const unsigned short *)&v;
+        } else {
+            const _Float16 v = (_Float16)f;
+            p[i] = *(const unsigned short *)&v;
+        }
+    }
+}
+
+extern "C" int nd_conv_bench(int kind, int dtype, int batch, int cin, int cout, int h, int w, int variant, int iters, void *ws,
                              size_t ws_bytes, void *stream, float *mean_ms) {
-    const size_t need = nd_layer_workspace_bytes(kind, batch, cin, cout, h, w, ND_F32);
-    const size_t wfloats = nd_packed_floats(kind, cin, cout);
+    const size_t need = nd_layer_workspace_bytes(kind, batch, cin, cout, h, w, dtype);
+    const size_t wfloats = need ? nd_packed_floats(kind, cin, cout, dtype) : 0;
     if (!need) ND_FAIL(ND_EINVAL, "nd_conv_bench: bad shape");
     const size_t total = need + ((wfloats * 4 + 255) & ~(size_t)255);
     if (!ws || ws_bytes < total) ND_FAIL(ND_ENOMEM, "nd_conv_bench: workspace %zu B given, %zu B needed", ws_bytes, total);
     hipStream_t s = (hipStream_t)stream;
-    LayerPlan pl = layer_plan(kind, batch, cin, cout, h, w, (char *)ws);
+    LayerPlan pl = layer_plan(kind, batch, cin, cout, h, w, (char *)ws, dtype);
     float *wpk = (float *)((char *)ws + need);
-    hipLaunchKernelGGL(k_fill_random, dim3(2048), dim3(256), 0, s, (float *)ws, need / 4, 12345u);
-    hipLaunchKernelGGL(k_fill_random, dim3(1024), dim3(256), 0, s, wpk, wfloats, 777u);
+    if (dtype == ND_F32) {
+        hipLaunchKernelGGL(k_fill_random, dim3(2048), dim3(256), 0, s, (float *)ws, need / 4, 12345u);
+        hipLaunchKernelGGL(k_fill_random, dim3(1024), dim3(256), 0, s, wpk, wfloats, 777u);
+    } else {
+        // pseudo-random finite 16-bit patterns: fill as bf16/fp16 values in (-0.5, 0.5) through the fp32 generator + convert
+        hipLaunchKernelGGL(k_fill_random16, dim3(2048), dim3(256), 0, s, (unsigned short *)ws, need / 2, 12345u, dtype);
+        hipLaunchKernelGGL(k_fill_random16, dim3(1024), dim3(256), 0, s, (unsigned short *)wpk, wfloats * 2, 777u, dtype);
+        hipLaunchKernelGGL(k_fill_random, dim3(64), dim3(256), 0, s, wpk + (size_t)nd_mtiles(kind, cout) * nd_kblocks(cin, dtype) * nd_taps(kind) * 256,
+                           (size_t)nd_mtiles(kind, cout) * 32, 99u);
+    }
     ConvDesc d;
     d.kind = kind;
     d.act = ND_ACT_PRELU;
@@ -536,18 +569,18 @@ extern "C" int nd_conv_bench(int kind, int batch, int cin, int cout, int h, int 
     d.cin = cin;
     d.cout = cout;
     d.wpk = wpk;
-    d.bias = wpk + (size_t)nd_mtiles(kind, cout) * nd_kblocks(cin) * nd_taps(kind) * 256;
+    d.bias = wpk + (size_t)nd_mtiles(kind, cout) * nd_kblocks(cin, dtype) * nd_taps(kind) * 256;
     d.in = pl.in;
     d.out = pl.out;
     d.out_plane0 = 0;
     d.variant = variant;
-    ND_TRY(nd_launch_conv_f32(d, s));  // warm-up (also validates the variant)
+    ND_TRY(nd_launch_conv(d, s));  // warm-up (also validates the variant)
     hipEvent_t e0, e1;
     ND_HIP(hipEventCreate(&e0));
     ND_HIP(hipEventCreate(&e1));
     ND_HIP(hipEventRecord(e0, s));
     int rc = ND_OK;
-    for (int i = 0; i < iters && rc == ND_OK; ++i) rc = nd_launch_conv_f32(d, s);
+    for (int i = 0; i < iters && rc == ND_OK; ++i) rc = nd_launch_conv(d, s);
     (void)hipEventRecord(e1, s);
     if (hipStreamSynchronize(s) != hipSuccess && rc == ND_OK) {
         nd_set_error("nd_conv_bench: stream failed");

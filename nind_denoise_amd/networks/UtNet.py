@@ -58,9 +58,22 @@ class UtNet(nn.Module):
         for name in order:
             g = groups[name]
             self.add_module(name, nn.Sequential(*[g[i] for i in sorted(g)]) if isinstance(g, dict) else g)
-        self._packed = None       # (key, device blob)
-        self._workspaces = {}     # (device, cs, batch) -> uint8 tensor
+        self._packed = {}         # dtype -> (key, device blob)
+        self._workspaces = {}     # (device, h, w, batch, dtype) -> uint8 tensor
         self.max_cached_workspaces = 2
+        self.compute_dtype = "f32"   # storage of activations + weights inside the conv stack: "f32" | "bf16" | "f16"
+
+    def set_compute_dtype(self, name):
+        """"f32": fp32 storage, exact-fp32 MFMA (the reference's arithmetic).  "bf16" / "f16": 16-bit storage of
+        activations and weights with fp32 accumulation (BASELINE configs 3 / 4); inputs and outputs stay float32."""
+        if name not in ("f32", "bf16", "f16"):
+            raise ValueError(f"unknown compute dtype {name!r}")
+        self.compute_dtype = name
+        return self
+
+    @property
+    def _dt(self):
+        return _lib.DTYPE[self.compute_dtype]
 
     # ------------------------------------------------------------------ weights
     def _weights_key(self, device):
@@ -69,8 +82,9 @@ class UtNet(nn.Module):
     def packed_weights(self, device):
         """Packed blob in HBM (re-packed when a parameter changed or moved)."""
         key = self._weights_key(device)
-        if self._packed is not None and self._packed[0] == key:
-            return self._packed[1]
+        hit = self._packed.get(self.compute_dtype)
+        if hit is not None and hit[0] == key:
+            return hit[1]
         lib = _lib.load()
         sd = self.state_dict()
         names = _lib.utnet_tensor_names()
@@ -83,30 +97,31 @@ class UtNet(nn.Module):
                 ptrs[i] = t.data_ptr()
             else:
                 ptrs[i] = None  # activation without parameters (ELU / Hardswish)
-        nbytes = lib.nd_utnet_packed_bytes(self.funit, _lib.ND_F32)
+        nbytes = lib.nd_utnet_packed_bytes(self.funit, self._dt)
         if nbytes == 0:
-            raise ValueError(f"UtNet: funit={self.funit} is not supported by the HIP path (multiple of 8 required)")
+            raise ValueError(f"UtNet: funit={self.funit} is not supported by the HIP path for {self.compute_dtype} "
+                             "(multiple of 8 for f32, of 16 for bf16 / f16)")
         blob = torch.empty(nbytes // 4, dtype=torch.float32)
-        _lib.check(lib.nd_utnet_pack_weights(self.funit, _lib.ND_F32, ptrs, len(names), blob.data_ptr(), nbytes),
+        _lib.check(lib.nd_utnet_pack_weights(self.funit, self._dt, ptrs, len(names), blob.data_ptr(), nbytes),
                    "nd_utnet_pack_weights")
         dev_blob = blob.to(device)
-        self._packed = (key, dev_blob)
+        self._packed[self.compute_dtype] = (key, dev_blob)
         return dev_blob
 
     def workspace(self, cs, batch, device, width=None):
         """Activation workspace for [batch,3,cs,width or cs] inputs (zero borders initialised once, then cached)."""
         h, w = int(cs), int(cs if width is None else width)
-        key = (str(device), h, w, int(batch))
+        key = (str(device), h, w, int(batch), self.compute_dtype)
         ws = self._workspaces.get(key)
         if ws is None:
             lib = _lib.load()
-            nbytes = lib.nd_utnet_workspace_bytes_hw(self.funit, h, w, batch, _lib.ND_F32)
+            nbytes = lib.nd_utnet_workspace_bytes_hw(self.funit, h, w, batch, self._dt)
             if nbytes == 0:
-                _lib.check(lib.nd_utnet_workspace_init_hw(None, 0, self.funit, h, w, batch, _lib.ND_F32, None), "UtNet")
+                _lib.check(lib.nd_utnet_workspace_init_hw(None, 0, self.funit, h, w, batch, self._dt, None), "UtNet")
             while len(self._workspaces) >= self.max_cached_workspaces:
                 self._workspaces.pop(next(iter(self._workspaces)))
             ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-            _lib.check(lib.nd_utnet_workspace_init_hw(ws.data_ptr(), nbytes, self.funit, h, w, batch, _lib.ND_F32,
+            _lib.check(lib.nd_utnet_workspace_init_hw(ws.data_ptr(), nbytes, self.funit, h, w, batch, self._dt,
                                                       _lib.stream_ptr(device)), "nd_utnet_workspace_init")
             self._workspaces[key] = ws
         return ws
@@ -129,7 +144,7 @@ class UtNet(nn.Module):
             blob = self.packed_weights(x.device)
             ws = self.workspace(h, batch, x.device, width=w)
             y = torch.empty_like(x)
-            _lib.check(lib.nd_utnet_forward_hw(self.funit, _lib.ACT[self.activation], _lib.ND_F32, blob.data_ptr(),
+            _lib.check(lib.nd_utnet_forward_hw(self.funit, _lib.ACT[self.activation], self._dt, blob.data_ptr(),
                                                x.data_ptr(), y.data_ptr(), batch, h, w, ws.data_ptr(), ws.numel(),
                                                _lib.stream_ptr(x.device)), "nd_utnet_forward")
         return y

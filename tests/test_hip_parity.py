@@ -43,22 +43,23 @@ def assert_close(y, ref, what=""):
 
 # ---------------------------------------------------------------------------- single layers
 
-def layer_forward(dev, kind, x, w, b, act="none", slope=0.25, variant=-1):
+def layer_forward(dev, kind, x, w, b, act="none", slope=0.25, variant=-1, dtype="f32"):
     lib = _lib.load()
     k = _lib.KIND[kind]
+    dt = _lib.DTYPE[dtype]
     B, cin, H, W = x.shape
     cout = w.shape[0] if kind in ("conv3", "conv1") else w.shape[1]
-    nbytes = lib.nd_layer_packed_bytes(k, cin, cout, _lib.ND_F32)
+    nbytes = lib.nd_layer_packed_bytes(k, cin, cout, dt)
     packed = torch.empty(nbytes // 4, dtype=torch.float32)
     wc, bc = w.contiguous(), b.contiguous()
-    _lib.check(lib.nd_layer_pack(k, cin, cout, _lib.ND_F32, wc.data_ptr(), bc.data_ptr(), packed.data_ptr(), nbytes))
+    _lib.check(lib.nd_layer_pack(k, cin, cout, dt, wc.data_ptr(), bc.data_ptr(), packed.data_ptr(), nbytes))
     packed = packed.to(dev)
     oh, ow = {"conv3": (H - 2, W - 2), "convT3": (H + 2, W + 2), "convT2s2": (2 * H, 2 * W), "conv1": (H, W)}[kind]
     y = torch.full((B, cout, oh, ow), float("nan"), dtype=torch.float32, device=dev)
-    wsb = lib.nd_layer_workspace_bytes(k, B, cin, cout, H, W, _lib.ND_F32)
+    wsb = lib.nd_layer_workspace_bytes(k, B, cin, cout, H, W, dt)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     xd = x.to(dev).contiguous()
-    _lib.check(lib.nd_layer_forward(k, _lib.ACT[act], slope, _lib.ND_F32, packed.data_ptr(), xd.data_ptr(), B, cin, H, W,
+    _lib.check(lib.nd_layer_forward(k, _lib.ACT[act], slope, dt, packed.data_ptr(), xd.data_ptr(), B, cin, H, W,
                                     cout, y.data_ptr(), ws.data_ptr(), wsb, variant, _lib.stream_ptr(dev)))
     torch.cuda.synchronize()
     return y
@@ -145,15 +146,23 @@ def test_every_conv_variant(dev):
     tested = 0
     for v in range(lib.nd_num_conv_variants()):
         name = lib.nd_conv_variant_name(v).decode()
+        dtype = name.split("_")[0]
+        tdt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[dtype]
+        q = (lambda t: t.to(tdt).float())       # what the 16-bit paths store
         if "_uptrue" in name:
-            y = layer_forward(dev, "convT2s2", x, up_w, b[:32], "none", variant=v)
-            ref = F.conv_transpose2d(x, up_w, b[:32], stride=2)
+            y = layer_forward(dev, "convT2s2", x, up_w, b[:32], "none", variant=v, dtype=dtype)
+            ref = F.conv_transpose2d(q(x), q(up_w), b[:32], stride=2)
         else:
             taps = 9 if "_t9_" in name else 1
             kind, w = cases[taps]
-            y = layer_forward(dev, kind, x, w, b, "PReLU", 0.2, variant=v)
-            ref = F.prelu(F.conv2d(x, w, b), torch.tensor([0.2]))
-        assert_close(y, ref, name)
+            y = layer_forward(dev, kind, x, w, b, "PReLU", 0.2, variant=v, dtype=dtype)
+            ref = F.prelu(F.conv2d(q(x), q(w), b), torch.tensor([0.2]))
+        if dtype == "f32":
+            assert_close(y, ref, name)
+        else:   # same 16-bit operands, fp32 accumulation; the stored result is rounded once to 16 bits
+            ulp = 2.0 ** (-8 if dtype == "bf16" else -11)
+            err = (y.cpu() - ref).abs()
+            assert (err <= ulp * ref.abs() + 1e-6).all(), (name, err.max().item())
         tested += 1
     assert tested == lib.nd_num_conv_variants()
 
@@ -439,3 +448,69 @@ def test_unet_tiled_frame_vs_oracle(dev):
     ref = otiler.denoise_frame(frame, cs, ucs, ol, model_fn, batch=4)
     out = pipeline.denoise_frame(net, torch.from_numpy(frame).to(dev), cs, ucs, ol, batch=5)
     assert_close(out, torch.from_numpy(ref), "unet frame")
+
+
+# ---------------------------------------------------------------------------- bf16 / fp16 storage (BASELINE configs 3, 4)
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_half_layers_exact_on_integer_data(dev, dtype):
+    # small integers are exact in bf16 / fp16 and fp32 accumulation of their products is exact: the only rounding is
+    # the final store, so the result must equal the 16-bit rounding of the exact answer bit for bit (pins the
+    # 32x32x16 fragment maps, the 8-channel plane layout, tap flips and the half-plane epilogue stores)
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    cin, cout, H, W = 32, 32, 12, 14
+    x = torch.arange(cin * H * W, dtype=torch.float32).reshape(1, cin, H, W) % 7 - 3
+    w = (torch.arange(cout * cin * 9, dtype=torch.float32).reshape(cout, cin, 3, 3) % 5) - 2
+    b = torch.arange(cout, dtype=torch.float32) - 16
+    y = layer_forward(dev, "conv3", x, w, b, "none", dtype=dtype)
+    assert torch.equal(y.cpu(), F.conv2d(x, w, b).to(tdt).float())
+    wt = (torch.arange(cout * cin * 9, dtype=torch.float32).reshape(cin, cout, 3, 3) % 5) - 2
+    y = layer_forward(dev, "convT3", x, wt, b, "PReLU", 0.5, dtype=dtype)
+    assert torch.equal(y.cpu(), F.prelu(F.conv_transpose2d(x, wt, b), torch.tensor([0.5])).to(tdt).float())
+    wu = (torch.arange(cout * cin * 4, dtype=torch.float32).reshape(cin, cout, 2, 2) % 5) - 2
+    y = layer_forward(dev, "convT2s2", x, wu, b, "none", dtype=dtype)
+    assert torch.equal(y.cpu(), F.conv_transpose2d(x, wu, b, stride=2).to(tdt).float())
+    x3 = torch.arange(3 * H * W, dtype=torch.float32).reshape(1, 3, H, W) % 5 - 2     # first layer: 3 -> one K block
+    w3 = (torch.arange(cout * 3 * 9, dtype=torch.float32).reshape(cout, 3, 3, 3) % 7) - 3
+    y = layer_forward(dev, "conv3", x3, w3, b, "none", dtype=dtype)
+    assert torch.equal(y.cpu(), F.conv2d(x3, w3, b).to(tdt).float())
+
+
+@pytest.mark.parametrize("dtype,min_psnr", [("bf16", 38.0), ("f16", 55.0)])
+def test_utnet_half_storage_vs_fp32_oracle(dev, golden_dir, dtype, min_psnr):
+    # configs 3 / 4: 16-bit storage, fp32 accumulate.  The 1e-3 bar is for fp32 only; here parity is reported as
+    # max-abs and PSNR against the fp32 reference output (peak = the reference's own range)
+    from nind_denoise_amd.networks.UtNet import UtNet
+    d = np.load(os.path.join(golden_dir, "utnet_f64_cs264.npz"))
+    sd = synth.make_utnet_state_dict(funit=64, seed=123)
+    net = UtNet()
+    net.load_state_dict(sd)
+    net = net.eval().to(dev).set_compute_dtype(dtype)
+    y = net(torch.from_numpy(d["x"]).to(dev)).cpu().numpy()
+    ref = d["y"]
+    assert np.isfinite(y).all()
+    err = np.abs(y - ref)
+    peak = float(ref.max() - ref.min())
+    psnr = 10 * np.log10(peak ** 2 / float(np.mean((y - ref) ** 2)))
+    print(f"UtNet(64) cs=264 {dtype}: max abs err {err.max():.3e}, PSNR {psnr:.1f} dB (peak {peak:.3f})")
+    assert psnr >= min_psnr, psnr
+    # and the fp32 path is untouched by switching back
+    net.set_compute_dtype("f32")
+    assert_close(net(torch.from_numpy(d["x"]).to(dev)), torch.from_numpy(ref), "fp32 after half")
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_frame_half_storage_fused_equals_unfused(dev, dtype):
+    from nind_denoise_amd import pipeline
+    from nind_denoise_amd.networks.UtNet import UtNet
+    net = UtNet(funit=16)
+    net.load_state_dict(synth.make_utnet_state_dict(funit=16, seed=9))
+    net = net.to(dev).set_compute_dtype(dtype)
+    img = torch.from_numpy(synth.make_frame(333, 290, seed=3)).to(dev)
+    a = pipeline.denoise_frame(net, img, 120, 88, 16, batch=5)
+    b = pipeline.denoise_frame(lambda x: net(x), img, 120, 88, 16, batch=3)
+    assert torch.equal(a, b)
+    net.set_compute_dtype("f32")
+    c = pipeline.denoise_frame(net, img, 120, 88, 16, batch=5)
+    rel = ((a - c).abs().max() / c.abs().max()).item()
+    assert rel < (0.05 if dtype == "bf16" else 0.01), rel

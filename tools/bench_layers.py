@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--variants", default="auto")
     ap.add_argument("--layers", default="")
+    ap.add_argument("--dtype", default="f32")
     args = ap.parse_args()
     lib = _lib.load()
     dev = torch.device("cuda:0")
@@ -65,11 +66,13 @@ def main():
         for v in cands:
             if v >= 0:
                 nm = names[v]
+                if not nm.startswith(args.dtype + "_"):
+                    continue
                 taps = 9 if "_t9_" in nm else 1
                 if (taps == 9) != (kind in ("conv3", "convT3")) or ("_uptrue" in nm) != (kind == "convT2s2"):
                     continue
             ms = ctypes.c_float()
-            rc = lib.nd_conv_bench(k, args.batch, cin, cout, h, h, v, args.iters, ws.data_ptr(), ws.numel(),
+            rc = lib.nd_conv_bench(k, _lib.DTYPE[args.dtype], args.batch, cin, cout, h, h, v, args.iters, ws.data_ptr(), ws.numel(),
                                    _lib.stream_ptr(dev), ms)
             if rc != 0:
                 print(f"{name:10s} v{v:<2d} skipped: {lib.nd_last_error().decode()}")
