@@ -1,0 +1,100 @@
+"""Resident multi-frame engine ("next" row f2 of SURVEY.md section 8).
+
+The reference pays model load + device init PER IMAGE: `denoise.py:430-436` and `denoise_dir.py:89-98` spawn one
+`denoise_image.py` process per frame.  `FrameEngine` keeps the packed weights and the activation workspace resident
+and streams frames through a small ring of slots so that, in steady state,
+
+    host->HBM copy of frame n+1   (copy stream, pinned staging)
+    crop -> UtNet -> stitch of n  (compute stream, device resident loop of pipeline.denoise_frame)
+    HBM->host copy of frame n-1   (copy-back stream, pinned staging)
+
+overlap.  Results come back in submission order.  Nothing here changes the arithmetic: a frame's canvas is bit-identical
+to `pipeline.denoise_frame` on the same frame.
+"""
+import collections
+
+import numpy as np
+import torch
+
+from . import pipeline
+
+
+class FrameEngine:
+    def __init__(self, model, width, height, cs, ucs, ol, batch=160, slots=3, device=None):
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if self.device.type != "cuda":
+            raise RuntimeError("FrameEngine needs a GPU (no CPU fallback)")
+        self.model, self.geom, self.batch = model, (cs, ucs, ol), batch
+        self.shape = (3, int(height), int(width))
+        self.total = pipeline.tile_count(width, height, cs, ucs, ol)
+        with torch.cuda.device(self.device):
+            self.compute = torch.cuda.Stream()
+            self.h2d = torch.cuda.Stream()
+            self.d2h = torch.cuda.Stream()
+            self.slots = []
+            for _ in range(max(2, slots)):
+                self.slots.append(dict(
+                    pin_in=torch.empty(self.shape, dtype=torch.float32).pin_memory(),
+                    pin_out=torch.empty(self.shape, dtype=torch.float32).pin_memory(),
+                    dev_in=torch.empty(self.shape, dtype=torch.float32, device=self.device),
+                    dev_out=torch.empty(self.shape, dtype=torch.float32, device=self.device),
+                    ev_in=torch.cuda.Event(), ev_done=torch.cuda.Event(), ev_out=torch.cuda.Event(), busy=False))
+        self.next = 0
+        self.inflight = collections.deque()
+        # allocate workspace / pack weights before the first frame (on the compute stream)
+        if hasattr(model, "packed_weights"):
+            with torch.cuda.device(self.device), torch.cuda.stream(self.compute):
+                model.packed_weights(self.device)
+                model.workspace(cs, min(batch, self.total), self.device)
+
+    def submit(self, frame):
+        """frame: float32 CHW numpy array / CPU tensor (or a CUDA tensor: then no host copy).  Non-blocking unless every
+        slot is still in flight."""
+        if len(self.inflight) == len(self.slots):
+            raise RuntimeError("all slots in flight: call collect() first")
+        slot = self.slots[self.next]
+        self.next = (self.next + 1) % len(self.slots)
+        if slot["busy"]:
+            slot["ev_out"].synchronize()
+        slot["busy"] = True
+        cs, ucs, ol = self.geom
+        with torch.cuda.device(self.device):
+            if isinstance(frame, torch.Tensor) and frame.is_cuda:
+                self.compute.wait_stream(torch.cuda.current_stream())
+                src = frame
+            else:
+                t = frame if isinstance(frame, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(frame, dtype=np.float32))
+                if tuple(t.shape) != self.shape:
+                    raise ValueError(f"frame shape {tuple(t.shape)} != engine shape {self.shape}")
+                slot["pin_in"].copy_(t)
+                with torch.cuda.stream(self.h2d):
+                    slot["dev_in"].copy_(slot["pin_in"], non_blocking=True)
+                    slot["ev_in"].record()
+                self.compute.wait_event(slot["ev_in"])
+                src = slot["dev_in"]
+            with torch.cuda.stream(self.compute):
+                slot["dev_out"].zero_()
+                pipeline.denoise_frame(self.model, src, cs, ucs, ol, batch=self.batch, canvas=slot["dev_out"])
+                slot["ev_done"].record()
+            with torch.cuda.stream(self.d2h):
+                self.d2h.wait_event(slot["ev_done"])
+                slot["pin_out"].copy_(slot["dev_out"], non_blocking=True)
+                slot["ev_out"].record()
+        self.inflight.append(slot)
+
+    def collect(self, copy=True):
+        """Oldest submitted frame's result as a numpy array (blocks until its copy-back has finished)."""
+        slot = self.inflight.popleft()
+        slot["ev_out"].synchronize()
+        slot["busy"] = False
+        out = slot["pin_out"].numpy()
+        return out.copy() if copy else out
+
+    def run(self, frames):
+        """Generator: denoise an iterable of frames, keeping the ring full; yields results in order."""
+        for f in frames:
+            if len(self.inflight) == len(self.slots):
+                yield self.collect()
+            self.submit(f)
+        while self.inflight:
+            yield self.collect()

@@ -514,3 +514,23 @@ def test_frame_half_storage_fused_equals_unfused(dev, dtype):
     c = pipeline.denoise_frame(net, img, 120, 88, 16, batch=5)
     rel = ((a - c).abs().max() / c.abs().max()).item()
     assert rel < (0.05 if dtype == "bf16" else 0.01), rel
+
+
+def test_frame_engine_streams_frames_in_order(dev):
+    # resident multi-frame engine: overlapped H2D / compute / D2H must not change a single bit and keeps the order
+    from nind_denoise_amd import pipeline
+    from nind_denoise_amd.networks.UtNet import UtNet
+    from nind_denoise_amd.serve import FrameEngine
+    net = UtNet(funit=16)
+    net.load_state_dict(synth.make_utnet_state_dict(funit=16, seed=2))
+    net = net.to(dev)
+    W, H, cs, ucs, ol = 300, 260, 120, 88, 16
+    frames = [synth.make_frame(W, H, seed=s) for s in range(7)]
+    eng = FrameEngine(net, W, H, cs, ucs, ol, batch=6, slots=3, device=dev)
+    outs = list(eng.run(frames))
+    assert len(outs) == len(frames)
+    for f, o in zip(frames, outs):
+        ref = pipeline.denoise_frame(net, torch.from_numpy(f).to(dev), cs, ucs, ol, batch=6).cpu().numpy()
+        assert np.array_equal(o, ref)
+    with pytest.raises(ValueError):
+        eng.submit(np.zeros((3, 10, 10), dtype=np.float32))
