@@ -534,3 +534,72 @@ def test_frame_engine_streams_frames_in_order(dev):
         assert np.array_equal(o, ref)
     with pytest.raises(ValueError):
         eng.submit(np.zeros((3, 10, 10), dtype=np.float32))
+
+
+def test_reference_style_main_loop_with_dataloader(dev):
+    # the reference's own loop shape (denoise_image.py:232-267): DataLoader over OneImageDS, model(ybatch), crop by
+    # usefuldim, make_seamless_edges, canvas += in tile order -- driven here with this package's drop-in classes only;
+    # must give the same bits as the fused device loop (row a4 / a8 of SURVEY.md section 8)
+    from torch.utils.data import DataLoader
+    from nind_denoise_amd import denoise_image as di
+    from nind_denoise_amd import pipeline
+    from nind_denoise_amd.networks.UtNet import UtNet
+    net = UtNet(funit=16)
+    net.load_state_dict(synth.make_utnet_state_dict(funit=16, seed=12))
+    net = net.eval().to(dev)
+    W, H, cs, ucs, ol = 333, 290, 120, 88, 16
+    frame = synth.make_frame(W, H, seed=4)
+    ds = di.OneImageDS(frame, cs, ucs, ol, device=dev)
+    loader = DataLoader(dataset=ds, num_workers=0, drop_last=False, batch_size=4, shuffle=False)
+    newimg = torch.zeros(3, H, W, dtype=torch.float32, device=dev)
+
+    def make_seamless_edges(tcrop, x0, y0):
+        if x0 != 0:
+            tcrop[:, :, 0:ol] = tcrop[:, :, 0:ol].div(2)
+        if y0 != 0:
+            tcrop[:, 0:ol, :] = tcrop[:, 0:ol, :].div(2)
+        if x0 + ucs < W and ol:
+            tcrop[:, :, -ol:] = tcrop[:, :, -ol:].div(2)
+        if y0 + ucs < H and ol:
+            tcrop[:, -ol:, :] = tcrop[:, -ol:, :].div(2)
+        return tcrop
+
+    n = 0
+    for ybatch, usefuldims, usefulstarts in loader:
+        assert ybatch.is_cuda and usefuldims.dtype == torch.int32
+        xbatch = net(ybatch)
+        for i in range(ybatch.size(0)):
+            ud = usefuldims[i]
+            t = xbatch[i][:, ud[1]:ud[3], ud[0]:ud[2]].clone()
+            ax, ay = tuple(usefulstarts[i].tolist())
+            t = make_seamless_edges(t, ax, ay)
+            newimg[:, ay:ay + t.shape[1], ax:ax + t.shape[2]] += t
+            n += 1
+    assert n == len(ds)
+    fused = pipeline.denoise_frame(net, torch.from_numpy(frame).to(dev), cs, ucs, ol, batch=7)
+    assert torch.equal(newimg, fused)
+
+
+def test_api_error_paths(dev):
+    lib = _lib.load()
+    from nind_denoise_amd import pipeline
+    img = torch.zeros(3, 300, 300, device=dev)
+    with pytest.raises(ValueError):
+        pipeline.gather_tiles(img, 264, 200, 64, 3, 5)          # tiles outside the grid
+    assert pipeline.gather_tiles(img, 264, 200, 64, 0, 0).shape[0] == 0   # empty range is a no-op
+    with pytest.raises(ValueError):
+        pipeline.tile_count(100, 100, 264, 200, 64)            # mirror padding would reach outside the frame
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device=dev)
+    blob = torch.zeros(1 << 10, device=dev)
+    x = torch.zeros(1, 3, 104, 104, device=dev)
+    rc = lib.nd_utnet_forward(16, 1, 0, blob.data_ptr(), x.data_ptr(), x.data_ptr(), 1, 104, ws.data_ptr(), ws.numel(),
+                              _lib.stream_ptr(dev))
+    assert rc == -2 and b"workspace" in lib.nd_last_error()      # ND_ENOMEM: workspace too small, nothing launched
+    rc = lib.nd_utnet_forward(12, 1, 0, blob.data_ptr(), x.data_ptr(), x.data_ptr(), 1, 104, ws.data_ptr(), ws.numel(),
+                              _lib.stream_ptr(dev))
+    assert rc == -1                                              # funit not a multiple of 8
+    rc = lib.nd_utnet_forward(16, 7, 0, blob.data_ptr(), x.data_ptr(), x.data_ptr(), 1, 104, ws.data_ptr(), ws.numel(),
+                              _lib.stream_ptr(dev))
+    assert rc == -1                                              # unknown activation
+    assert lib.nd_utnet_workspace_bytes(16, 104, 1, 1) > 0 and lib.nd_utnet_workspace_bytes(8, 104, 1, 1) == 0   # bf16 needs funit%16
+    torch.cuda.synchronize()
