@@ -267,7 +267,7 @@ def main():
             }
         if not args.no_cpu_baseline and world == 1:
             threads = min(host_cores(), 64)
-            n = args.cpu_sample_tiles or max(8, min(96, threads * 4))
+            n = args.cpu_sample_tiles or max(8, min(320, threads * 16))   # ~15 s of CPU work at ~0.05 s/tile
             log(f"cpu baseline: {n} tiles on {threads} threads")
             cdt, tot = cpu_baseline(frame_np, sd, cs, ucs, ol, n, threads)
             log(f"cpu baseline done in {cdt:.1f} s")

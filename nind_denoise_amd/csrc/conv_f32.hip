@@ -65,7 +65,7 @@ static int pick_variant(const ConvDesc &d, int M) {
         return g0 + 2;
     }
     if (KB % 2) return g0 + (up ? 7 : 5);
-    if (up) return g0 + (M >= 128 ? 8 : 6);
+    if (up) return g0 + (M >= 128 ? (KB % 4 == 0 ? 10 : 8) : (KB % 4 == 0 ? 9 : 6));
     return g0 + 4;
 }
 
