@@ -62,7 +62,6 @@ def main():
         if want and name not in want:
             continue
         k = _lib.KIND[kind]
-        base = {"f32": 0, "bf16": 1, "f16": 2}[args.dtype] * lib.nd_num_conv_variants() // 3 if False else 0
         cands = [-1] if args.variants == "auto" else [int(v) for v in args.variants.split(",")]
         for v in cands:
             if v >= 0:
