@@ -96,7 +96,7 @@ def conv_stack_profile(net, cs, batch, dev, reps=3):
 
 
 def pmc_traffic(cs, batch, funit):
-    """HBM bytes per launch of the dominant kernel (the 3x3 conv_qp_f32 variant) from the committed rocprofv3 PMC passes
+    """HBM bytes per launch of the dominant kernel (the fp32 3x3 conv_qp variants) from the committed rocprofv3 PMC passes
     (FETCH_SIZE and WRITE_SIZE collected in separate runs, gfx950 read correction applied -- profiles/*_pmc_summary.json).
     Counters cannot be read inside the timed run, so this is null unless a profile of the same configuration exists."""
     import glob
@@ -109,11 +109,16 @@ def pmc_traffic(cs, batch, funit):
         c = d.get("config", {})
         if (c.get("cs"), c.get("tiles_per_launch"), c.get("funit")) != (cs, batch, funit):
             continue
-        for name, v in d.get("kernels", {}).items():
-            if "conv_qp_f32" in name and ", 9, " in name and "hbm_read_bytes_mean" in v:
-                return {"bytes_per_launch": round(v["hbm_read_bytes_mean"] + v["hbm_write_bytes_mean"]),
-                        "read": round(v["hbm_read_bytes_mean"]), "write": round(v["hbm_write_bytes_mean"]),
-                        "source": os.path.relpath(f, ROOT)}
+        rd = wr = n = 0
+        for name, v in d.get("kernels", {}).items():   # every fp32 3x3 variant of the dominant kernel, dispatch weighted
+            if name.startswith("conv_qp<0,") and ", 9, 1, false" in name and "hbm_read_bytes_mean" in v:
+                k = v["FETCH_SIZE"]["dispatches"]
+                rd += v["hbm_read_bytes_mean"] * k
+                wr += v["hbm_write_bytes_mean"] * k
+                n += k
+        if n:
+            return {"bytes_per_launch": round((rd + wr) / n), "read": round(rd / n), "write": round(wr / n),
+                    "launches_profiled": n, "source": os.path.relpath(f, ROOT)}
     return None
 
 
