@@ -41,7 +41,8 @@ typedef enum nd_layer_kind {
     ND_CONV3 = 0,         /* nn.Conv2d(k=3, valid)            UtNet.py:29..54          */
     ND_CONVT3 = 1,        /* nn.ConvTranspose2d(k=3, s=1)     UtNet.py:56,61,63,...    */
     ND_CONVT2S2 = 2,      /* nn.ConvTranspose2d(k=2, s=2)     UtNet.py:59,66,73,80     */
-    ND_CONV1 = 3          /* nn.Conv2d(k=1)                   UtNet.py:86              */
+    ND_CONV1 = 3,         /* nn.Conv2d(k=1)                   UtNet.py:86              */
+    ND_CONV2S2 = 4        /* nn.Conv2d(k=2, stride=2): the data gradient of ConvTranspose2d(2, s=2) (training step) */
 } nd_layer_kind;
 
 typedef enum nd_dtype {

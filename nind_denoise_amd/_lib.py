@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libnind_hip.so")
 ND_F32, ND_BF16, ND_F16 = 0, 1, 2
 DTYPE = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "f16": 2, "fp16": 2, "float16": 2}
 ACT = {"none": 0, "PReLU": 1, "ELU": 2, "Hardswish": 3}
-KIND = {"conv3": 0, "convT3": 1, "convT2s2": 2, "conv1": 3}
+KIND = {"conv3": 0, "convT3": 1, "convT2s2": 2, "conv1": 3, "conv2s2": 4}
 
 
 class NindHipError(RuntimeError):

@@ -24,13 +24,20 @@ int nd_conv_variant_count() { return g_nvariants; }
 const char *nd_conv_variant_label(int v) { return (v >= 0 && v < g_nvariants) ? variant_at(v).name : ""; }
 
 // Largest input span (pixels) of one N tile + 3x3 halo.  cross = tiles may run across image boundaries.
+static void valid_grid(int taps, const QpBuf &in, int *Hv, int *Wv, int *stride) {
+    *stride = taps == 4 ? 2 : 1;
+    *Hv = taps == 9 ? in.Hb - 2 : (taps == 4 ? in.Hb / 2 : in.Hb);
+    *Wv = taps == 9 ? in.Wb - 2 : (taps == 4 ? in.Wb / 2 : in.Wb);
+}
 static int tile_span(const Variant &V, const QpBuf &in, bool cross) {
     const int taps = V.taps;
-    const int Hv = taps == 9 ? in.Hb - 2 : in.Hb, Wv = taps == 9 ? in.Wb - 2 : in.Wb;
+    int Hv, Wv, s;
+    valid_grid(taps, in, &Hv, &Wv, &s);
     const int n = V.nblk;
-    int span = n + (in.Wb - Wv) * ((n - 1) / Wv + 1);
-    if (cross) span += (in.Hb - Hv) * in.Wb * ((n - 1) / (Hv * Wv) + 1);
-    if (taps == 9) span += 2 * in.Wb + 2;
+    // consecutive valid pixels are s input pixels apart; every row end adds s*(Wb - Wv), every image end the rest of the image
+    int span = s * n + s * (in.Wb - Wv) * ((n - 1) / Wv + 1);
+    if (cross) span += (in.Hb * in.Wb - Hv * s * in.Wb) * ((n - 1) / (Hv * Wv) + 1);
+    span += taps == 9 ? 2 * in.Wb + 2 : (taps == 4 ? in.Wb + 1 : 0);
     return span;
 }
 static size_t lds_for(const Variant &V, int G) {
@@ -65,7 +72,8 @@ static int pick_variant(const ConvDesc &d, int M) {
             // two shapes compete: 64x512 tiles on three LDS stages and 64x1024 tiles (64x128 per wave: a third less LDS-DMA
             // per FLOP, measured ~4.5 % cheaper per pixel) on two.  The bigger tile loses when the tile count quantises badly
             // against the CU count, so compare whole rounds.
-            const int Hv = d.in.Hb - 2, Wv = d.in.Wb - 2;
+            int Hv, Wv, st_;
+            valid_grid(9, d.in, &Hv, &Wv, &st_);
             const int cus = g_num_cus > 0 ? g_num_cus : 256;
             double best = 0;
             int best_v = -1;
@@ -90,6 +98,7 @@ static int pick_variant(const ConvDesc &d, int M) {
             if (variant_lds(variant_at(g0 + v), d.in) <= kMaxLds) return g0 + v;
         return g0 + 2;
     }
+    if (taps == 4) return g0 + (variant_lds(variant_at(g0 + 12), d.in) <= kMaxLds ? 12 : 13);
     if (KB % 2) return g0 + (up ? 7 : 5);
     if (up) return g0 + (M >= 128 ? (KB % 4 == 0 ? 10 : 8) : (KB % 4 == 0 ? 9 : 6));
     return g0 + 4;
@@ -132,9 +141,9 @@ int nd_launch_conv(const ConvDesc &d, hipStream_t stream) {
     p.nimg = d.in.B;
     p.P = d.in.Hb * d.in.Wb;
     p.Wb = d.in.Wb;
-    p.Hv = taps == 9 ? d.in.Hb - 2 : d.in.Hb;
-    p.Wv = taps == 9 ? d.in.Wb - 2 : d.in.Wb;
+    valid_grid(taps, d.in, &p.Hv, &p.Wv, &p.stride);
     p.PV = p.Hv * p.Wv;
+    if (taps == 4 && (d.in.pad != 0 || (d.in.Hb | d.in.Wb) & 1)) ND_FAIL(ND_EINVAL, "conv: the stride-2 layer reads unbordered even-sized buffers only");
     p.KB = KB;
     p.M = M;
     p.cout = d.cout;

@@ -71,7 +71,7 @@ const char *nd_conv_variant_label(int v);
 static inline int nd_mtiles(int kind, int cout) {
     return kind == ND_CONVT2S2 ? (4 * cout + 255) / 256 * 8 : (cout + 127) / 128 * 4;   // up layers use 256-row workgroup tiles
 }
-static inline int nd_taps(int kind) { return (kind == ND_CONV3 || kind == ND_CONVT3) ? 9 : 1; }
+static inline int nd_taps(int kind) { return (kind == ND_CONV3 || kind == ND_CONVT3) ? 9 : (kind == ND_CONV2S2 ? 4 : 1); }
 // K block = two planes = the K extent of one ds_read_b128 per operand: 8 fp32 channels or 16 bf16/fp16 channels
 static inline int nd_kblocks(int cin, int dt = ND_F32) { return (cin + 2 * nd_cpp(dt) - 1) / (2 * nd_cpp(dt)); }
 // packed layer size in 4-byte units: 1 KiB fragment pieces [mtile][kb][tap] (any dtype) + fp32 bias[mtiles*32]

@@ -11,6 +11,7 @@
 //                                                                                  zero-bordered input)
 //     CONVT2S2 Weff[(a,b,co)][ci]    = w[ci][co][a][b],  m = (2a+b)*Cout + co     (w: [Cin,Cout,2,2])
 //     CONV1    Weff[co][ci]          = w[co][ci]
+//     CONV2S2  Weff[co][ci][(a,b)]   = w[co][ci][a][b]                           (w: [Cout,Cin,2,2], stride 2)
 // bf16 / fp16: the same order with 8 channels per lane (ci = 16*kb + 8*h + s), values rounded to nearest even.
 #include <string.h>
 
@@ -59,6 +60,7 @@ void nd_pack_layer(int kind, int cin, int cout, int dt, const float *w, const fl
                 const int ab = m / cout, co = m - ab * cout;
                 return w[((size_t)ci * cout + co) * 4 + ab];
             }
+            case ND_CONV2S2: return w[((size_t)m * cin + ci) * 4 + t];
             default: return w[(size_t)m * cin + ci];
         }
     };
@@ -87,14 +89,14 @@ void nd_pack_layer(int kind, int cin, int cout, int dt, const float *w, const fl
 }
 
 extern "C" size_t nd_layer_packed_bytes(int kind, int cin, int cout, int dtype) {
-    if (dtype < ND_F32 || dtype > ND_F16 || kind < 0 || kind > 3 || cin <= 0 || cout <= 0) return 0;
+    if (dtype < ND_F32 || dtype > ND_F16 || kind < 0 || kind > 4 || cin <= 0 || cout <= 0) return 0;
     return nd_packed_floats(kind, cin, cout, dtype) * sizeof(float);
 }
 
 extern "C" int nd_layer_pack(int kind, int cin, int cout, int dtype, const float *weight, const float *bias,
                              void *packed_host, size_t packed_bytes) {
     if (dtype < ND_F32 || dtype > ND_F16) ND_FAIL(ND_EINVAL, "nd_layer_pack: unsupported dtype %d", dtype);
-    if (kind < 0 || kind > 3 || cin <= 0 || cout <= 0 || !weight || !packed_host)
+    if (kind < 0 || kind > 4 || cin <= 0 || cout <= 0 || !weight || !packed_host)
         ND_FAIL(ND_EINVAL, "nd_layer_pack: bad arguments");
     if (packed_bytes < nd_layer_packed_bytes(kind, cin, cout, dtype))
         ND_FAIL(ND_ENOMEM, "nd_layer_pack: packed buffer too small");

@@ -441,6 +441,7 @@ LayerPlan layer_plan(int kind, int B, int cin, int cout, int h, int w, char *bas
         case ND_CONV3: oh = h - 2; ow = w - 2; break;
         case ND_CONVT3: oh = h + 2; ow = w + 2; break;
         case ND_CONVT2S2: oh = 2 * h; ow = 2 * w; break;
+        case ND_CONV2S2: oh = h / 2; ow = w / 2; break;
         default: oh = h; ow = w; break;
     }
     p.out.planes = (cout + nd_cpp(dt) - 1) / nd_cpp(dt);
@@ -457,7 +458,7 @@ LayerPlan layer_plan(int kind, int B, int cin, int cout, int h, int w, char *bas
 }  // namespace
 
 extern "C" size_t nd_layer_workspace_bytes(int kind, int batch, int cin, int cout, int h, int w, int dtype) {
-    if (dtype < ND_F32 || dtype > ND_F16 || kind < 0 || kind > 3 || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return 0;
+    if (dtype < ND_F32 || dtype > ND_F16 || kind < 0 || kind > 4 || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return 0;
     if (kind == ND_CONV3 && (h < 3 || w < 3)) return 0;
     return layer_plan(kind, batch, cin, cout, h, w, nullptr, dtype).bytes;
 }

@@ -48,13 +48,14 @@ def layer_forward(dev, kind, x, w, b, act="none", slope=0.25, variant=-1, dtype=
     k = _lib.KIND[kind]
     dt = _lib.DTYPE[dtype]
     B, cin, H, W = x.shape
-    cout = w.shape[0] if kind in ("conv3", "conv1") else w.shape[1]
+    cout = w.shape[0] if kind in ("conv3", "conv1", "conv2s2") else w.shape[1]
     nbytes = lib.nd_layer_packed_bytes(k, cin, cout, dt)
     packed = torch.empty(nbytes // 4, dtype=torch.float32)
     wc, bc = w.contiguous(), b.contiguous()
     _lib.check(lib.nd_layer_pack(k, cin, cout, dt, wc.data_ptr(), bc.data_ptr(), packed.data_ptr(), nbytes))
     packed = packed.to(dev)
-    oh, ow = {"conv3": (H - 2, W - 2), "convT3": (H + 2, W + 2), "convT2s2": (2 * H, 2 * W), "conv1": (H, W)}[kind]
+    oh, ow = {"conv3": (H - 2, W - 2), "convT3": (H + 2, W + 2), "convT2s2": (2 * H, 2 * W), "conv1": (H, W),
+              "conv2s2": (H // 2, W // 2)}[kind]
     y = torch.full((B, cout, oh, ow), float("nan"), dtype=torch.float32, device=dev)
     wsb = lib.nd_layer_workspace_bytes(k, B, cin, cout, H, W, dt)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
@@ -140,7 +141,8 @@ def test_layer_asymmetric_identity(dev):
 def test_every_conv_variant(dev):
     lib = _lib.load()
     x = rnd((2, 64, 36, 40), 5)
-    cases = {9: ("conv3", rnd((128, 64, 3, 3), 6, 0.07)), 1: ("conv1", rnd((128, 64, 1, 1), 7, 0.2))}
+    cases = {9: ("conv3", rnd((128, 64, 3, 3), 6, 0.07)), 1: ("conv1", rnd((128, 64, 1, 1), 7, 0.2)),
+             4: ("conv2s2", rnd((128, 64, 2, 2), 10, 0.1))}
     up_w = rnd((64, 32, 2, 2), 8, 0.1)
     b = rnd((128,), 9, 0.1)
     tested = 0
@@ -153,10 +155,10 @@ def test_every_conv_variant(dev):
             y = layer_forward(dev, "convT2s2", x, up_w, b[:32], "none", variant=v, dtype=dtype)
             ref = F.conv_transpose2d(q(x), q(up_w), b[:32], stride=2)
         else:
-            taps = 9 if "_t9_" in name else 1
+            taps = 9 if "_t9_" in name else (4 if "_t4_" in name else 1)
             kind, w = cases[taps]
             y = layer_forward(dev, kind, x, w, b, "PReLU", 0.2, variant=v, dtype=dtype)
-            ref = F.prelu(F.conv2d(q(x), q(w), b), torch.tensor([0.2]))
+            ref = F.prelu(F.conv2d(q(x), q(w), b, stride=2 if taps == 4 else 1), torch.tensor([0.2]))
         if dtype == "f32":
             assert_close(y, ref, name)
         else:   # same 16-bit operands, fp32 accumulation; the stored result is rounded once to 16 bits
@@ -603,3 +605,35 @@ def test_api_error_paths(dev):
     assert rc == -1                                              # unknown activation
     assert lib.nd_utnet_workspace_bytes(16, 104, 1, 1) > 0 and lib.nd_utnet_workspace_bytes(8, 104, 1, 1) == 0   # bf16 needs funit%16
     torch.cuda.synchronize()
+
+
+# ---------------------------------------------------------------------------- training step building blocks
+
+def test_backward_data_through_the_forward_kernels(dev):
+    # data gradients of the three layer types are forward launches of the SAME conv kernel with the weight tensor
+    # re-read in its transposed role (no copy): dgrad(Conv2d) = ConvTranspose2d, dgrad(ConvTranspose2d) = Conv2d,
+    # dgrad(ConvTranspose2d(2, s=2)) = Conv2d(2, stride=2).  Checked against torch autograd.
+    zero = lambda n: torch.zeros(n)
+    x = rnd((2, 24, 20, 18), 1).requires_grad_()
+    w = rnd((40, 24, 3, 3), 2, 0.1)
+    dy = rnd((2, 40, 18, 16), 3)
+    F.conv2d(x, w).backward(dy)
+    assert_close(layer_forward(dev, "convT3", dy, w, zero(24)), x.grad, "dgrad conv3")
+
+    x = rnd((2, 16, 11, 13), 4).requires_grad_()
+    wt = rnd((16, 32, 3, 3), 5, 0.1)
+    dy = rnd((2, 32, 13, 15), 6)
+    F.conv_transpose2d(x, wt).backward(dy)
+    assert_close(layer_forward(dev, "conv3", dy, wt, zero(16)), x.grad, "dgrad convT3")
+
+    for (ci, co, h, w_) in ((64, 32, 13, 13), (16, 8, 9, 7), (128, 64, 30, 26)):
+        x = rnd((2, ci, h, w_), 7).requires_grad_()
+        wu = rnd((ci, co, 2, 2), 8, 0.2)
+        dy = rnd((2, co, 2 * h, 2 * w_), 9)
+        F.conv_transpose2d(x, wu, stride=2).backward(dy)
+        assert_close(layer_forward(dev, "conv2s2", dy, wu, zero(ci)), x.grad, f"dgrad convT2s2 {ci}->{co}")
+    # exact-integer pin of the stride-2 tap / lane maps
+    xi = (torch.arange(16 * 12 * 10, dtype=torch.float32).reshape(1, 16, 12, 10) % 7) - 3
+    wi = (torch.arange(8 * 16 * 4, dtype=torch.float32).reshape(8, 16, 2, 2) % 5) - 2
+    y = layer_forward(dev, "conv2s2", xi, wi, torch.arange(8, dtype=torch.float32))
+    assert torch.equal(y.cpu(), F.conv2d(xi, wi, torch.arange(8, dtype=torch.float32), stride=2))

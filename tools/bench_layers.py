@@ -68,6 +68,8 @@ def main():
                 nm = names[v]
                 if not nm.startswith(args.dtype + "_"):
                     continue
+                if "_t4_" in nm:
+                    continue
                 taps = 9 if "_t9_" in nm else 1
                 if (taps == 9) != (kind in ("conv3", "convT3")) or ("_uptrue" in nm) != (kind == "convT2s2"):
                     continue
