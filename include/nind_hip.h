@@ -155,6 +155,15 @@ int nd_layer_forward(int kind, int act, float slope, int dtype, const void *pack
 int nd_maxpool2_forward(const float *x_nchw, int batch, int c, int h, int w, float *y_nchw,
                         void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---------------------------------------------------------------- training-step building blocks (next row f3)
+ * Weight and bias gradient of one layer (autograd's conv backward-weight; nn_common.py:201-218 loss.backward()):
+ * x [B,cin,h,w] = the layer's input, dy = gradient w.r.t. the layer's (pre-activation) output, NCHW fp32 in HBM;
+ * dw in the torch weight layout of the layer kind, db [cout].  The data gradient of a layer is a FORWARD launch of the
+ * transposed kind (nd_layer_forward: CONV3 <-> CONVT3, CONVT2S2 -> CONV2S2) on the same weight tensor. */
+size_t nd_layer_wgrad_workspace_bytes(int kind, int batch, int cin, int cout, int h, int w);
+int nd_layer_wgrad(int kind, const float *x_nchw, const float *dy_nchw, int batch, int cin, int h, int w, int cout,
+                   float *dw, float *db, void *workspace, size_t workspace_bytes, void *stream);
+
 /* Kernel micro-benchmark: `iters` launches of one conv layer (variant -1 = automatic choice) on pseudo-random
  * quad-planar data carved from `workspace` (nd_layer_workspace_bytes + nd_layer_packed_bytes + 256 B); mean launch
  * duration from HIP events on `stream`.  Synchronises the stream. */

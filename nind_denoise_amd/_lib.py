@@ -60,6 +60,8 @@ _SIGNATURES = {
     "nd_layer_forward": (c_int, [c_int, c_int, c_float, c_int, c_void_p, c_void_p] + [c_int] * 5
                          + [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "nd_maxpool2_forward": (c_int, [c_void_p] + [c_int] * 4 + [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "nd_layer_wgrad_workspace_bytes": (c_size_t, [c_int] * 6),
+    "nd_layer_wgrad": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "nd_conv_bench": (c_int, [c_int] * 9 + [c_void_p, c_size_t, c_void_p, POINTER(c_float)]),
     "nd_num_conv_variants": (c_int, []),
     "nd_conv_variant_name": (c_char_p, [c_int]),

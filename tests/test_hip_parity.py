@@ -637,3 +637,49 @@ def test_backward_data_through_the_forward_kernels(dev):
     wi = (torch.arange(8 * 16 * 4, dtype=torch.float32).reshape(8, 16, 2, 2) % 5) - 2
     y = layer_forward(dev, "conv2s2", xi, wi, torch.arange(8, dtype=torch.float32))
     assert torch.equal(y.cpu(), F.conv2d(xi, wi, torch.arange(8, dtype=torch.float32), stride=2))
+
+
+WGRAD_CASES = [
+    # kind, B, cin, cout, H, W
+    ("conv3", 2, 24, 40, 20, 18),
+    ("conv3", 3, 64, 64, 34, 30),
+    ("conv3", 2, 3, 64, 40, 36),          # first layer: 3 input channels
+    ("conv3", 1, 128, 72, 13, 13),
+    ("convT3", 2, 16, 32, 11, 13),
+    ("convT3", 1, 128, 64, 26, 22),
+    ("convT2s2", 2, 64, 32, 13, 13),
+    ("convT2s2", 1, 16, 8, 9, 7),
+    ("conv1", 2, 64, 4, 21, 23),
+    ("conv3", 4, 64, 64, 138, 138),       # many K slices (training-size rows)
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES, ids=lambda c: "-".join(str(v) for v in c))
+def test_weight_gradient_vs_autograd(dev, case):
+    kind, B, cin, cout, H, W = case
+    lib = _lib.load()
+    k = {"conv3": 3, "convT3": 3, "convT2s2": 2, "conv1": 1}[kind]
+    x = rnd((B, cin, H, W), 1)
+    wshape = (cout, cin, k, k) if kind in ("conv3", "conv1") else (cin, cout, k, k)
+    w = rnd(wshape, 2, 0.1).requires_grad_()
+    b = rnd((cout,), 3, 0.1).requires_grad_()
+    if kind in ("conv3", "conv1"):
+        y = F.conv2d(x, w, b)
+    else:
+        y = F.conv_transpose2d(x, w, b, stride=2 if kind == "convT2s2" else 1)
+    dy = rnd(tuple(y.shape), 4)
+    y.backward(dy)
+    wsb = lib.nd_layer_wgrad_workspace_bytes(_lib.KIND[kind], B, cin, cout, H, W)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    dw = torch.full(wshape, float("nan"), device=dev)
+    db = torch.full((cout,), float("nan"), device=dev)
+    xd, dyd = x.to(dev).contiguous(), dy.to(dev).contiguous()
+    _lib.check(lib.nd_layer_wgrad(_lib.KIND[kind], xd.data_ptr(), dyd.data_ptr(), B, cin, H, W, cout, dw.data_ptr(),
+                                  db.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr(dev)))
+    torch.cuda.synchronize()
+    # sums of up to ~1e5 products of O(1) values: compare relative to the gradient's own scale
+    for got, ref, what in ((dw, w.grad, "dW"), (db, b.grad, "db")):
+        got = got.cpu()
+        assert torch.isfinite(got).all(), what
+        err = (got - ref).abs().max().item()
+        assert err <= 2e-5 * max(ref.abs().max().item(), 1.0) + 1e-5, (case, what, err, ref.abs().max().item())
