@@ -164,6 +164,24 @@ size_t nd_layer_wgrad_workspace_bytes(int kind, int batch, int cin, int cout, in
 int nd_layer_wgrad(int kind, const float *x_nchw, const float *dy_nchw, int batch, int cin, int h, int w, int cout,
                    float *dw, float *db, void *workspace, size_t workspace_bytes, void *stream);
 
+/* UtNet training step (BASELINE config 5; nn_train.py:308-380, nn_common.py:198-255), PReLU networks, fp32.
+ * Parameters and gradients are flat float buffers in state-dict order (nd_utnet_tensor_name / nd_utnet_param_range):
+ * one buffer for the data-parallel all-reduce and for the optimizer.  nd_utnet_train_step = device-side weight
+ * packing + forward + loss + backward:
+ *     loss = w_l1 * mean|clip(y,0,1) - target| + w_mse * mean (clip(y,0,1) - target)^2        (y = net(x))
+ * x, target, y_out: [batch,3,cs,cs] NCHW fp32 in HBM (cs = 16k+56, e.g. 136 / 184); loss_out: one float in HBM.
+ * nd_adam_step = torch.optim.Adam(lr, betas, eps, amsgrad) on the flat buffers (nn_common.py:185). */
+size_t nd_utnet_param_count(int funit);
+int nd_utnet_param_range(int funit, int tensor_idx, size_t *offset, size_t *count);
+size_t nd_utnet_train_blob_bytes(int funit);
+size_t nd_utnet_train_workspace_bytes(int funit, int cs, int batch);
+int nd_utnet_train_workspace_init(void *workspace, size_t workspace_bytes, int funit, int cs, int batch, void *stream);
+int nd_utnet_train_step(int funit, const float *params, float *grads, void *blobs, const float *x_nchw,
+                        const float *target_nchw, float *y_out_nchw, float w_l1, float w_mse, float *loss_out,
+                        int batch, int cs, void *workspace, size_t workspace_bytes, void *stream);
+int nd_adam_step(float *params, const float *grads, float *m, float *v, float *vmax, size_t n, float lr, float beta1,
+                 float beta2, float eps, int step, int amsgrad, void *stream);
+
 /* Kernel micro-benchmark: `iters` launches of one conv layer (variant -1 = automatic choice) on pseudo-random
  * quad-planar data carved from `workspace` (nd_layer_workspace_bytes + nd_layer_packed_bytes + 256 B); mean launch
  * duration from HIP events on `stream`.  Synchronises the stream. */

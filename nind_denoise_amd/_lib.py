@@ -62,6 +62,14 @@ _SIGNATURES = {
     "nd_maxpool2_forward": (c_int, [c_void_p] + [c_int] * 4 + [c_void_p, c_void_p, c_size_t, c_void_p]),
     "nd_layer_wgrad_workspace_bytes": (c_size_t, [c_int] * 6),
     "nd_layer_wgrad": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "nd_utnet_param_count": (c_size_t, [c_int]),
+    "nd_utnet_param_range": (c_int, [c_int, c_int, POINTER(c_size_t), POINTER(c_size_t)]),
+    "nd_utnet_train_blob_bytes": (c_size_t, [c_int]),
+    "nd_utnet_train_workspace_bytes": (c_size_t, [c_int] * 3),
+    "nd_utnet_train_workspace_init": (c_int, [c_void_p, c_size_t, c_int, c_int, c_int, c_void_p]),
+    "nd_utnet_train_step": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
+                                    c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "nd_adam_step": (c_int, [c_void_p] * 5 + [c_size_t, c_float, c_float, c_float, c_float, c_int, c_int, c_void_p]),
     "nd_conv_bench": (c_int, [c_int] * 9 + [c_void_p, c_size_t, c_void_p, POINTER(c_float)]),
     "nd_num_conv_variants": (c_int, []),
     "nd_conv_variant_name": (c_char_p, [c_int]),

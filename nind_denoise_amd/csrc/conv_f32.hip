@@ -24,10 +24,12 @@ int nd_conv_variant_count() { return g_nvariants; }
 const char *nd_conv_variant_label(int v) { return (v >= 0 && v < g_nvariants) ? variant_at(v).name : ""; }
 
 // Largest input span (pixels) of one N tile + 3x3 halo.  cross = tiles may run across image boundaries.
+// 3x3 layers consume the border of their input buffer as padding (valid grid = buffer - 2); 1- and 4-tap layers read the
+// interior of a possibly bordered buffer
 static void valid_grid(int taps, const QpBuf &in, int *Hv, int *Wv, int *stride) {
     *stride = taps == 4 ? 2 : 1;
-    *Hv = taps == 9 ? in.Hb - 2 : (taps == 4 ? in.Hb / 2 : in.Hb);
-    *Wv = taps == 9 ? in.Wb - 2 : (taps == 4 ? in.Wb / 2 : in.Wb);
+    *Hv = taps == 9 ? in.Hb - 2 : (in.Hb - 2 * in.pad) / *stride;
+    *Wv = taps == 9 ? in.Wb - 2 : (in.Wb - 2 * in.pad) / *stride;
 }
 static int tile_span(const Variant &V, const QpBuf &in, bool cross) {
     const int taps = V.taps;
@@ -114,7 +116,7 @@ int nd_launch_conv(const ConvDesc &d, hipStream_t stream) {
     const int KB = nd_kblocks(d.cin, dt);
     const int M = up ? 4 * d.cout : d.cout;
     if (d.cout % nd_cpp(dt)) ND_FAIL(ND_EINVAL, "conv: cout=%d must be a multiple of %d", d.cout, nd_cpp(dt));
-    if (d.in.planes < 2 * KB) ND_FAIL(ND_EINVAL, "conv: input buffer has %d planes, needs %d", d.in.planes, 2 * KB);
+    if (d.in.planes < d.in_plane0 + 2 * KB) ND_FAIL(ND_EINVAL, "conv: input buffer has %d planes, needs %d", d.in.planes, d.in_plane0 + 2 * KB);
     const long NP = d.in.used();
     if (NP >= (1L << 31)) ND_FAIL(ND_EINVAL, "conv: %ld linear pixels exceed the int32 index range", NP);
 
@@ -132,7 +134,7 @@ int nd_launch_conv(const ConvDesc &d, hipStream_t stream) {
     if (KB % V.kbc) ND_FAIL(ND_EINVAL, "conv: Cin/8=%d not a multiple of the variant's K chunk %d", KB, V.kbc);
 
     ConvParams p;
-    p.in = (const f32x4 *)d.in.base;
+    p.in = (const f32x4 *)d.in.base + (long)d.in_plane0 * d.in.np();
     p.wpk = d.wpk;
     p.bias = d.bias;
     p.out = (f32x4 *)d.out.base;
@@ -143,7 +145,11 @@ int nd_launch_conv(const ConvDesc &d, hipStream_t stream) {
     p.Wb = d.in.Wb;
     valid_grid(taps, d.in, &p.Hv, &p.Wv, &p.stride);
     p.PV = p.Hv * p.Wv;
-    if (taps == 4 && (d.in.pad != 0 || (d.in.Hb | d.in.Wb) & 1)) ND_FAIL(ND_EINVAL, "conv: the stride-2 layer reads unbordered even-sized buffers only");
+    if (taps == 4 && ((d.in.Hb | d.in.Wb) & 1)) ND_FAIL(ND_EINVAL, "conv: the stride-2 layer reads even-sized buffers only");
+    p.ioff = taps == 9 ? 0 : d.in.pad * d.in.Wb + d.in.pad;
+    p.pre = (f32x4 *)d.pre;
+    p.pre_plane = d.pre_plane;
+    if (d.pre && (dt != ND_F32 || up)) ND_FAIL(ND_EINVAL, "conv: the pre-activation copy exists for fp32 non-upsampling layers only");
     p.KB = KB;
     p.M = M;
     p.cout = d.cout;
@@ -157,7 +163,6 @@ int nd_launch_conv(const ConvDesc &d, hipStream_t stream) {
 
     // destination geometry must hold the result
     const int oh = up ? 2 * p.Hv : p.Hv, ow = up ? 2 * p.Wv : p.Wv;
-    if (taps == 1 && d.in.pad != 0) ND_FAIL(ND_EINVAL, "conv: 1-tap layers read unbordered buffers only");
     // (a 2x2 stride-2 result may be smaller than its destination: UNet's F.pad fix-up for odd sizes, ThirdPartyNets.py:110-118)
     const bool fits = up ? (d.out.Hb >= oh + 2 * d.out.pad && d.out.Wb >= ow + 2 * d.out.pad)
                          : (d.out.Hb == oh + 2 * d.out.pad && d.out.Wb == ow + 2 * d.out.pad);

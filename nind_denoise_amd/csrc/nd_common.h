@@ -60,6 +60,9 @@ struct ConvDesc {
     QpBuf out;          // destination buffer (possibly a concat buffer)
     int out_plane0;     // first destination plane (channel offset / 4) inside `out`
     int variant;        // -1: pick automatically
+    int in_plane0 = 0;  // first input plane inside `in` (a channel slice of a concat / gradient buffer)
+    float *pre = nullptr;   // training: also store the pre-activation (acc + bias), compact [C/4][B][Hv][Wv] float4 planes
+    long pre_plane = 0;     // 16-byte elements per plane of `pre`
 };
 int nd_launch_conv(const ConvDesc &d, hipStream_t stream);
 static inline int nd_launch_conv_f32(const ConvDesc &d, hipStream_t stream) { return nd_launch_conv(d, stream); }

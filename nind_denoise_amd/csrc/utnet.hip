@@ -9,219 +9,7 @@
 
 #include "nd_common.h"
 
-namespace {
-
-struct LayerSpec {
-    const char *key;
-    int kind;
-    int cin_mul, cout_mul;  // channels = mul * funit (cin_mul 0 -> 3 input channels, cout_mul 0 -> 3 output channels)
-    int prelu;              // index into the slope table, -1: no activation
-};
-
-// forward order; prelu indices follow the state-dict order of the activation modules
-const LayerSpec kLayers[] = {
-    {"convs1.0", ND_CONV3, 0, 1, 0},    {"convs1.2", ND_CONV3, 1, 1, 1},    {"convs2.0", ND_CONV3, 1, 2, 2},
-    {"convs2.2", ND_CONV3, 2, 2, 3},    {"convs3.0", ND_CONV3, 2, 4, 4},    {"convs3.2", ND_CONV3, 4, 4, 5},
-    {"convs4.0", ND_CONV3, 4, 8, 6},    {"convs4.2", ND_CONV3, 8, 8, 7},    {"bottom.0", ND_CONV3, 8, 16, 8},
-    {"bottom.2", ND_CONVT3, 16, 16, 9}, {"up1", ND_CONVT2S2, 16, 8, -1},    {"tconvs1.0", ND_CONVT3, 16, 8, 10},
-    {"tconvs1.2", ND_CONVT3, 8, 8, 11}, {"up2", ND_CONVT2S2, 8, 4, -1},     {"tconvs2.0", ND_CONVT3, 8, 4, 12},
-    {"tconvs2.2", ND_CONVT3, 4, 4, 13}, {"up3", ND_CONVT2S2, 4, 2, -1},     {"tconvs3.0", ND_CONVT3, 4, 2, 14},
-    {"tconvs3.2", ND_CONVT3, 2, 2, 15}, {"up4", ND_CONVT2S2, 2, 1, -1},     {"tconvs4.0", ND_CONVT3, 2, 1, 16},
-    {"tconvs4.2", ND_CONVT3, 1, 1, 17}, {"tconvs4.4", ND_CONV1, 1, 0, -1},
-};
-constexpr int kNumLayers = (int)(sizeof(kLayers) / sizeof(kLayers[0]));
-constexpr int kNumSlopes = 18;
-constexpr int kHeaderFloats = 32;  // slope table (18 used)
-
-// state-dict order of the reference module (UtNet.py:27-88): weight, bias of every layer, PReLU weights interleaved
-std::vector<std::string> build_tensor_names() {
-    std::vector<std::string> n;
-    auto seq = [&](const std::string &p, int n_act_pairs, bool final1x1) {
-        for (int k = 0; k < n_act_pairs; ++k) {
-            n.push_back(p + "." + std::to_string(2 * k) + ".weight");
-            n.push_back(p + "." + std::to_string(2 * k) + ".bias");
-            n.push_back(p + "." + std::to_string(2 * k + 1) + ".weight");
-        }
-        if (final1x1) {
-            n.push_back(p + ".4.weight");
-            n.push_back(p + ".4.bias");
-        }
-    };
-    for (int i = 1; i <= 4; ++i) seq("convs" + std::to_string(i), 2, false);
-    seq("bottom", 2, false);
-    for (int i = 1; i <= 4; ++i) {
-        n.push_back("up" + std::to_string(i) + ".weight");
-        n.push_back("up" + std::to_string(i) + ".bias");
-        seq("tconvs" + std::to_string(i), 2, i == 4);
-    }
-    return n;
-}
-const std::vector<std::string> &tensor_names() {
-    static const std::vector<std::string> n = build_tensor_names();
-    return n;
-}
-int tensor_index(const std::string &name) {
-    const auto &n = tensor_names();
-    for (size_t i = 0; i < n.size(); ++i)
-        if (n[i] == name) return (int)i;
-    return -1;
-}
-
-inline int lcin(const LayerSpec &l, int f) { return l.cin_mul ? l.cin_mul * f : 3; }
-inline int lcout(const LayerSpec &l, int f) { return l.cout_mul ? l.cout_mul * f : 3; }
-
-// float offsets of every layer inside the packed blob
-struct BlobLayout {
-    size_t off[kNumLayers];
-    size_t total;
-};
-BlobLayout blob_layout(int f, int dt) {
-    BlobLayout b;
-    size_t o = kHeaderFloats;
-    for (int i = 0; i < kNumLayers; ++i) {
-        b.off[i] = o;
-        const LayerSpec &l = kLayers[i];
-        if (i == kNumLayers - 1)
-            o += ((size_t)3 * lcin(l, f) + 3 + 3) / 4 * 4;  // raw [3][cin] + bias[3] for the VALU 1x1 kernel
-        else
-            o += nd_packed_floats(l.kind, lcin(l, f), lcout(l, f), dt);
-    }
-    b.total = o;
-    return b;
-}
-
-bool valid_cs(int cs) { return cs >= 104 && (cs - 56) % 16 == 0; }
-
-int check_funit(int funit, int dtype) {
-    if (dtype < ND_F32 || dtype > ND_F16) ND_FAIL(ND_EINVAL, "UtNet: unsupported dtype %d", dtype);
-    const int q = 2 * nd_cpp(dtype);   // every conv input must be whole K blocks: 8 (fp32) / 16 (bf16, fp16) channels
-    if (funit < q || funit % q) ND_FAIL(ND_EINVAL, "UtNet: funit=%d must be a positive multiple of %d for dtype %d", funit, q, dtype);
-    return ND_OK;
-}
-
-int check_net(int funit, int h, int w, int batch, int dtype) {
-    ND_TRY(check_funit(funit, dtype));
-    for (int cs : {h, w})
-        if (!valid_cs(cs))
-            ND_FAIL(ND_EINVAL, "UtNet: tile size %d is not of the form 16k+56 (104, 120, ..., 248, 264, ..., 504, 520); "
-                               "the reference network rejects it too (sizes of the skip concats do not match)", cs);
-    if (batch <= 0) ND_FAIL(ND_EINVAL, "UtNet: batch=%d", batch);
-    return ND_OK;
-}
-
-// ---------------------------------------------------------------- workspace plan
-enum Buf { X0, A1, CAT4, P1, A2, CAT3, P2, A3, CAT2, P3, A4, CAT1, P4, BT0, BT1, T1A, T1B, T2A, T2B, T3A, T3B, T4A, T4B, NBUF };
-
-struct Plan {
-    QpBuf buf[NBUF];
-    size_t bytes;
-};
-
-// cap = batch the workspace was sized for; nimg = images in use (<= cap)
-Plan make_plan(int f, int ch_, int cw_, int cap, int nimg, char *base, int dt) {
-    Plan p;
-    size_t off = 0;
-    // `size` is the extent of the tensor for a SQUARE cs x cs input; the other dimension follows the same chain
-    auto chain = [](int cs, int which) {
-        const int l1 = cs, l2 = cs / 2 - 4, l3 = l2 / 2 - 4, l4 = l3 / 2 - 4, p4 = l4 / 2;
-        const int v[] = {cs + 4, cs + 2, l1, l1 / 2, l1 / 2 - 2, l2, l2 / 2, l2 / 2 - 2, l3, l3 / 2, l3 / 2 - 2, l4, p4,
-                         p4 - 2, p4, l4 + 2, l4 + 4, l3 + 2, l3 + 4, l2 + 2, l2 + 4, l1 + 2, l1 + 4};
-        return v[which];
-    };
-    auto add = [&](Buf id, int ch, int /*size*/, int pad) {
-        QpBuf &q = p.buf[id];
-        q.planes = (ch + nd_cpp(dt) - 1) / nd_cpp(dt);
-        if (id == X0) q.planes = 2;   // one K block: plane 0 = (r,g,b,0..), plane 1 = zeros
-        q.dt = dt;
-        q.B = nimg;
-        q.Hb = chain(ch_, (int)id) + 2 * pad;
-        q.Wb = chain(cw_, (int)id) + 2 * pad;
-        q.pad = pad;
-        q.pstride = (long)cap * q.Hb * q.Wb;
-        q.base = (float *)(base + off);
-        // slack: an N tile may read (tile + 3x3 halo) pixels past the last plane
-        const size_t slack = (size_t)(2 * q.Wb + 2 + 2048);
-        off += ((size_t)q.planes * q.pstride + slack) * 16;
-        off = (off + 255) & ~(size_t)255;
-    };
-    const int cs = ch_;
-    const int l1 = cs, l2 = cs / 2 - 4, l3 = l2 / 2 - 4, l4 = l3 / 2 - 4, p4 = l4 / 2;
-    add(X0, 8, cs + 4, 0);
-    add(A1, f, cs + 2, 0);
-    add(CAT4, 2 * f, l1, 2);
-    add(P1, f, l1 / 2, 0);
-    add(A2, 2 * f, l1 / 2 - 2, 0);
-    add(CAT3, 4 * f, l2, 2);
-    add(P2, 2 * f, l2 / 2, 0);
-    add(A3, 4 * f, l2 / 2 - 2, 0);
-    add(CAT2, 8 * f, l3, 2);
-    add(P3, 4 * f, l3 / 2, 0);
-    add(A4, 8 * f, l3 / 2 - 2, 0);
-    add(CAT1, 16 * f, l4, 2);
-    add(P4, 8 * f, p4, 0);
-    add(BT0, 16 * f, p4 - 2, 2);
-    add(BT1, 16 * f, p4, 0);
-    add(T1A, 8 * f, l4 + 2, 2);
-    add(T1B, 8 * f, l4 + 4, 0);
-    add(T2A, 4 * f, l3 + 2, 2);
-    add(T2B, 4 * f, l3 + 4, 0);
-    add(T3A, 2 * f, l2 + 2, 2);
-    add(T3B, 2 * f, l2 + 4, 0);
-    add(T4A, f, l1 + 2, 2);
-    add(T4B, f, l1 + 4, 0);
-    p.bytes = off;
-    return p;
-}
-
-struct Step {
-    int layer;  // index into kLayers, or -1 for a pool
-    Buf src, dst;
-    int dst_plane0_mul;  // destination plane offset = mul * funit / 4
-};
-// the conv stack between the input pack and the final 1x1 (UtNet.py:99-107)
-constexpr int kNumSteps = 26;
-const Step kSteps[kNumSteps] = {
-    {0, X0, A1, 0},     {1, A1, CAT4, 1},   {-1, CAT4, P1, 1},  {2, P1, A2, 0},    {3, A2, CAT3, 2},  {-1, CAT3, P2, 2},
-    {4, P2, A3, 0},     {5, A3, CAT2, 4},   {-1, CAT2, P3, 4},  {6, P3, A4, 0},    {7, A4, CAT1, 8},  {-1, CAT1, P4, 8},
-    {8, P4, BT0, 0},    {9, BT0, BT1, 0},   {10, BT1, CAT1, 0}, {11, CAT1, T1A, 0}, {12, T1A, T1B, 0}, {13, T1B, CAT2, 0},
-    {14, CAT2, T2A, 0}, {15, T2A, T2B, 0},  {16, T2B, CAT3, 0}, {17, CAT3, T3A, 0}, {18, T3A, T3B, 0}, {19, T3B, CAT4, 0},
-    {20, CAT4, T4A, 0}, {21, T4A, T4B, 0},
-};
-
-// ev (optional): kNumSteps+1 events, ev[i] recorded before step i, ev[kNumSteps] after the last one
-int run_stack(int f, int act, int dt, const float *blob, const Plan &pl, hipStream_t s, hipEvent_t *ev = nullptr) {
-    const BlobLayout bl = blob_layout(f, dt);
-    const int cpp = nd_cpp(dt);
-    int si = 0;
-    for (const Step &st : kSteps) {
-        if (ev) ND_HIP(hipEventRecord(ev[si], s));
-        ++si;
-        if (st.layer < 0) {
-            // pool reads the skip half of the concat buffer: planes [mul*f/4, 2*mul*f/4)
-            ND_TRY(nd_launch_maxpool2(pl.buf[st.src], st.dst_plane0_mul * f / cpp, st.dst_plane0_mul * f / cpp, pl.buf[st.dst], s));
-            continue;
-        }
-        const LayerSpec &l = kLayers[st.layer];
-        ConvDesc d;
-        d.kind = l.kind;
-        d.act = l.prelu >= 0 ? act : ND_ACT_NONE;
-        d.slope = 0.25f;
-        d.slope_dev = (l.prelu >= 0 && act == ND_ACT_PRELU) ? blob + l.prelu : nullptr;
-        d.cin = lcin(l, f);
-        d.cout = lcout(l, f);
-        d.wpk = blob + bl.off[st.layer];
-        d.bias = d.wpk + (size_t)nd_mtiles(l.kind, d.cout) * nd_kblocks(d.cin, dt) * nd_taps(l.kind) * 256;
-        d.in = pl.buf[st.src];
-        d.out = pl.buf[st.dst];
-        d.out_plane0 = st.dst_plane0_mul * f / cpp;
-        d.variant = -1;
-        ND_TRY(nd_launch_conv(d, s));
-    }
-    if (ev) ND_HIP(hipEventRecord(ev[si], s));
-    return ND_OK;
-}
-
-}  // namespace
+#include "utnet_net.h"
 
 // ------------------------------------------------------------------ C ABI
 extern "C" int nd_utnet_num_tensors(void) { return (int)tensor_names().size(); }

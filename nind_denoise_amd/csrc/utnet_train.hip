@@ -1,0 +1,589 @@
+// UtNet training step (forward + loss + backward) -- BASELINE config 5 / SURVEY.md section 8(f) rank 3.
+// Reference: nn_train.py:308-380 (loop), nn_common.py:198-255 (denoise_batch = model(x).clip(0,1); compute_loss;
+// loss.backward(); Adam(amsgrad).step()).
+//
+// Everything heavy reuses the inference machinery:
+//   forward        the inference launch sequence (run_stack) with the conv epilogue also storing acc + bias ("pre")
+//   data gradient  the SAME conv kernel on the weight tensor read in its transposed role:
+//                  dgrad(Conv2d) = ConvTranspose2d, dgrad(ConvTranspose2d) = Conv2d, dgrad(ConvT 2x2 s2) = Conv 2x2 s2
+//   weight gradient k_wgrad (wgrad.hip): MFMA contraction over pixels on a common grid (k_repitch)
+// Small HBM-bound kernels below: PReLU backward (+ slope gradient), max-pool backward, final 1x1 backward, loss, bias
+// sums, device-side weight packing, Adam(amsgrad).
+// Gradients come out in ONE flat fp32 buffer in state-dict order, so the data-parallel all-reduce (RCCL) and the
+// optimizer are single flat operations.
+#include <math.h>
+
+#include "utnet_net.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+int nd_launch_repitch(const QpBuf &src, int src_plane0, int planes, int ss, int sy, int sx, const QpBuf &dst, int oy,
+                      int ox, int h, int w, hipStream_t s);
+size_t nd_wgrad_partial_floats(int taps, int M, int N, long K, int *ksplit_out, int *cps_out);
+int nd_launch_wgrad(const QpBuf &A, int a_plane0, int M, const QpBuf &Bq, int b_plane0, int N, int taps, int taps_total,
+                    int tap0, float *partial, size_t partial_floats, float *dw, hipStream_t s);
+int nd_launch_channel_sum(const QpBuf &src, int plane0, int C, float *out, hipStream_t s);
+
+// ------------------------------------------------------------------ elementwise kernels
+// g (interior of a bordered gradient buffer, planes [plane0, plane0+planes)) *= prelu'(pre);  partial[block] = sum g*pre over pre <= 0
+__global__ __launch_bounds__(256) void k_prelu_bwd(f32x4 *__restrict__ g, long gnp, int gHb, int gWb, int gpad,
+                                                   const f32x4 *__restrict__ pre, long pnp, int H, int W,
+                                                   const float *__restrict__ slope, float *__restrict__ partial) {
+    __shared__ float red[256];
+    const int b = blockIdx.x, q = blockIdx.y;
+    const float a = *slope;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < H * W; i += 256) {
+        const int y = i / W, x = i - y * W;
+        f32x4 *gp = g + (long)q * gnp + ((long)b * gHb + y + gpad) * gWb + x + gpad;
+        const f32x4 pv = pre[(long)q * pnp + (long)b * H * W + i];
+        f32x4 gv = *gp;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (!(pv[e] > 0.f)) {
+                acc += gv[e] * pv[e];
+                gv[e] *= a;
+            }
+        }
+        *gp = gv;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[(long)q * gridDim.x + b] = red[0];
+}
+
+// out[0] = scale * sum partial[0..n)   (one workgroup, fixed order)
+__global__ __launch_bounds__(256) void k_sum_partials(const float *__restrict__ partial, int n, float scale, float *__restrict__ out) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0] * scale;
+}
+
+// gfine[argmax of each 2x2 window] += gpool   (fwd: the forward values that were pooled; first maximum in row-major order)
+__global__ void k_maxpool_bwd_add(const f32x4 *__restrict__ gpool, long pnp, int pHb, int pWb, int ppad,
+                                  const f32x4 *__restrict__ fwd, long fnp, int fHb, int fWb, int fpad,
+                                  f32x4 *__restrict__ gfine, long gnp, int gHb, int gWb, int gpad, int Ho, int Wo, int B) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int b = blockIdx.z % B, q = blockIdx.z / B;
+    if (x >= Wo) return;
+    const f32x4 gv = gpool[(long)q * pnp + ((long)b * pHb + y + ppad) * pWb + x + ppad];
+    const f32x4 *f = fwd + (long)q * fnp + ((long)b * fHb + 2 * y + fpad) * fWb + 2 * x + fpad;
+    f32x4 *g = gfine + (long)q * gnp + ((long)b * gHb + 2 * y + gpad) * gWb + 2 * x + gpad;
+    const f32x4 v[4] = {f[0], f[1], f[fWb], f[fWb + 1]};
+    f32x4 o[4] = {g[0], g[1], g[gWb], g[gWb + 1]};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        int best = 0;
+        float m = v[0][e];
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+            if (v[k][e] > m) {
+                m = v[k][e];
+                best = k;
+            }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k == best) o[k][e] += gv[e];
+    }
+    g[0] = o[0];
+    g[1] = o[1];
+    g[gWb] = o[2];
+    g[gWb + 1] = o[3];
+}
+
+// loss = w_l1 * mean|clip(y) - t| + w_mse * mean (clip(y) - t)^2 ;  gy = d loss / d y   (nn_common.py:198-199, 236-255)
+__global__ __launch_bounds__(256) void k_loss_grad(const float *__restrict__ y, const float *__restrict__ t, long n, float w_l1,
+                                                   float w_mse, float *__restrict__ gy, float *__restrict__ partial) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    const float inv = 1.f / (float)n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float v = y[i];
+        const float c = fminf(fmaxf(v, 0.f), 1.f);
+        const float d = c - t[i];
+        acc += w_l1 * fabsf(d) + w_mse * d * d;
+        const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        const float pass = (v >= 0.f && v <= 1.f) ? 1.f : 0.f;   // clamp passes the gradient on [min, max]
+        gy[i] = pass * (w_l1 * sgn + w_mse * 2.f * d) * inv;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// data gradient of the final Conv2d(f,3,1) + crop: g[c][b][Y][X] = sum_co gy[co][b][Y-crop][X-crop] * w[co][c] (0 outside)
+__global__ void k_final_bwd_data(const float *__restrict__ gy, int S, const float *__restrict__ w, int cin, int crop,
+                                 f32x4 *__restrict__ g, long gnp, int Hb, int Wb, int B) {
+    const int X = blockIdx.x * blockDim.x + threadIdx.x;
+    const int Y = blockIdx.y;
+    const int b = blockIdx.z % B, q = blockIdx.z / B;
+    if (X >= Wb) return;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    const int yy = Y - crop, xx = X - crop;
+    if (yy >= 0 && yy < S && xx >= 0 && xx < S) {
+        const float *p = gy + ((long)b * 3 * S + yy) * S + xx;
+        const float g0 = p[0], g1 = p[(long)S * S], g2 = p[2 * (long)S * S];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * q + e;
+            if (c < cin) o[e] = g0 * w[c] + g1 * w[cin + c] + g2 * w[2 * cin + c];
+        }
+    }
+    g[(long)q * gnp + ((long)b * Hb + Y) * Wb + X] = o;
+}
+
+// weight / bias gradient of the final 1x1: one workgroup per (co, plane); dw[co][4q..4q+3], db[co] (plane 0 only)
+__global__ __launch_bounds__(256) void k_final_wgrad(const float *__restrict__ gy, int S, const f32x4 *__restrict__ act, long anp,
+                                                     int Hb, int Wb, int crop, int B, int cin, float *__restrict__ dw,
+                                                     float *__restrict__ db) {
+    __shared__ f32x4 red[256];
+    __shared__ float redb[256];
+    const int co = blockIdx.x, q = blockIdx.y;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float accb = 0.f;
+    const long total = (long)B * S * S;
+    for (long i = threadIdx.x; i < total; i += 256) {
+        const int b = (int)(i / ((long)S * S));
+        const int r = (int)(i - (long)b * S * S);
+        const int y = r / S, x = r - y * S;
+        const float gv = gy[(((long)b * 3 + co) * S + y) * S + x];
+        acc += act[(long)q * anp + ((long)b * Hb + y + crop) * Wb + x + crop] * gv;
+        accb += gv;
+    }
+    red[threadIdx.x] = acc;
+    redb[threadIdx.x] = accb;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) {
+            red[threadIdx.x] += red[threadIdx.x + k];
+            redb[threadIdx.x] += redb[threadIdx.x + k];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 4 && 4 * q + (int)threadIdx.x < cin) dw[(long)co * cin + 4 * q + threadIdx.x] = red[0][threadIdx.x];
+    if (threadIdx.x == 0 && q == 0) db[co] = redb[0];
+}
+
+// device-side weight packing (same map as pack.hip's host packer, fp32): nw packed weights followed by MT*32 biases
+__global__ void k_pack_dev(int kind, int cin, int cout, int M, int KB, int taps, const float *__restrict__ w,
+                           const float *__restrict__ bias, float *__restrict__ packed, long nw, int nb) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < nw) {
+        const int s = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+        long rest = idx >> 8;
+        const int t = (int)(rest % taps);
+        rest /= taps;
+        const int kb = (int)(rest % KB), mt = (int)(rest / KB);
+        const int m = 32 * mt + (lane & 31), ci = 8 * kb + 4 * (lane >> 5) + s;
+        float v = 0.f;
+        if (m < M && ci < cin) {
+            switch (kind) {
+                case ND_CONV3: v = w[((long)m * cin + ci) * 9 + t]; break;
+                case ND_CONVT3: v = w[((long)ci * cout + m) * 9 + (8 - t)]; break;
+                case ND_CONVT2S2: {
+                    const int ab = m / cout, co = m - ab * cout;
+                    v = w[((long)ci * cout + co) * 4 + ab];
+                    break;
+                }
+                case ND_CONV2S2: v = w[((long)m * cin + ci) * 4 + t]; break;
+                default: v = w[(long)m * cin + ci]; break;
+            }
+        }
+        packed[idx] = v;
+    } else if (idx < nw + nb) {
+        const int m = (int)(idx - nw);
+        packed[idx] = (m < M && bias) ? bias[kind == ND_CONVT2S2 ? m % cout : m] : 0.f;
+    }
+}
+
+// Adam with amsgrad, torch.optim.Adam semantics (nn_common.py:185): no weight decay
+__global__ void k_adam(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
+                       float *__restrict__ vmax, long n, float lr, float b1, float b2, float eps, float bc1, float bc2,
+                       int amsgrad) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    float vd = vi;
+    if (amsgrad) {
+        vd = fmaxf(vmax[i], vi);
+        vmax[i] = vd;
+    }
+    const float denom = sqrtf(vd) / sqrtf(bc2) + eps;
+    p[i] -= (lr / bc1) * mi / denom;
+}
+
+namespace {
+
+inline int transposed_kind(int kind) {
+    return kind == ND_CONV3 ? ND_CONVT3 : (kind == ND_CONVT3 ? ND_CONV3 : (kind == ND_CONVT2S2 ? ND_CONV2S2 : -1));
+}
+
+// flat parameter layout = state-dict order (nd_utnet_tensor_name)
+struct ParamLayout {
+    std::vector<size_t> off, cnt;
+    size_t total;
+};
+ParamLayout param_layout(int f) {
+    ParamLayout pl;
+    size_t o = 0;
+    for (const std::string &name : tensor_names()) {
+        size_t n = 1;   // PReLU slope
+        for (int i = 0; i < kNumLayers; ++i) {
+            const LayerSpec &l = kLayers[i];
+            const int k = l.kind == ND_CONV1 ? 1 : (l.kind == ND_CONVT2S2 ? 2 : 3);
+            if (name == std::string(l.key) + ".weight") n = (size_t)lcin(l, f) * lcout(l, f) * k * k;
+            if (name == std::string(l.key) + ".bias") n = (size_t)lcout(l, f);
+        }
+        pl.off.push_back(o);
+        pl.cnt.push_back(n);
+        o += n;
+    }
+    pl.total = o;
+    return pl;
+}
+// name of the PReLU tensor that follows layer `key` in its Sequential
+std::string prelu_name(const char *key) {
+    std::string k(key);
+    const size_t dot = k.rfind('.');
+    return k.substr(0, dot + 1) + std::to_string(atoi(k.c_str() + dot + 1) + 1) + ".weight";
+}
+
+struct BwdBlob {   // dgrad weights: per layer the transposed-kind packing (none for layer 0 and the final 1x1)
+    size_t off[kNumLayers];
+    size_t total;
+};
+BwdBlob bwd_blob_layout(int f) {
+    BwdBlob b;
+    size_t o = 0;
+    for (int i = 0; i < kNumLayers; ++i) {
+        b.off[i] = o;
+        const LayerSpec &l = kLayers[i];
+        if (i == 0 || l.kind == ND_CONV1) continue;
+        o += nd_packed_floats(transposed_kind(l.kind), lcout(l, f), lcin(l, f), ND_F32);
+    }
+    b.total = o;
+    return b;
+}
+
+struct TrainPlan {
+    Plan fwd;
+    QpBuf pre[kNumSlopes];
+    QpBuf g[NBUF];
+    QpBuf scratch;          // re-pitched wgrad operand (largest over the layers)
+    float *partial;         // wgrad K-slice partial sums
+    size_t partial_floats;
+    float *red;             // reduction scratch
+    float *gy;              // d loss / d output  [B,3,S,S]
+    size_t bytes;
+};
+constexpr int kRedFloats = 1 << 16;
+
+int step_of_layer(int layer) {
+    for (int i = 0; i < kNumSteps; ++i)
+        if (kSteps[i].layer == layer) return i;
+    return -1;
+}
+// pad of a gradient buffer: 2 when the tensor is produced by a Conv2d(3) layer (its data gradient is a transpose conv,
+// which reads a zero-bordered input), else 0
+int grad_pad(Buf id) {
+    switch (id) {
+        case A1: case A2: case A3: case A4: case BT0: case CAT1: case CAT2: case CAT3: case CAT4: return 2;
+        default: return 0;
+    }
+}
+
+TrainPlan make_train_plan(int f, int cs, int B, char *base) {
+    TrainPlan t;
+    t.fwd = make_plan(f, cs, cs, B, B, base, ND_F32);
+    size_t off = t.fwd.bytes;
+    auto alloc = [&](QpBuf &q, int planes, int Hb, int Wb, int pad) {
+        q.planes = planes;
+        q.B = B;
+        q.Hb = Hb;
+        q.Wb = Wb;
+        q.pad = pad;
+        q.dt = ND_F32;
+        q.pstride = (long)B * Hb * Wb;
+        q.base = (float *)(base ? base + off : nullptr);
+        off += ((size_t)planes * q.pstride + 2 * Wb + 2 + 2048) * 16;
+        off = (off + 255) & ~(size_t)255;
+    };
+    // pre-activation copies: compact, the layer's output size
+    for (int i = 0; i < kNumLayers; ++i) {
+        const LayerSpec &l = kLayers[i];
+        if (l.prelu < 0) continue;
+        const QpBuf &o = t.fwd.buf[kSteps[step_of_layer(i)].dst];
+        alloc(t.pre[l.prelu], lcout(l, f) / 4, o.Hb - 2 * o.pad, o.Wb - 2 * o.pad, 0);
+    }
+    // gradient buffers
+    size_t scratch_elems = 0;
+    for (int id = 1; id < NBUF; ++id) {
+        const QpBuf &o = t.fwd.buf[id];
+        const int pad = grad_pad((Buf)id);
+        alloc(t.g[id], o.planes, o.Hb - 2 * o.pad + 2 * pad, o.Wb - 2 * o.pad + 2 * pad, pad);
+    }
+    t.g[X0] = QpBuf();
+    // scratch + wgrad partials: maxima over the layers
+    size_t pf = 0;
+    for (int i = 0; i < kNumLayers - 1; ++i) {
+        const LayerSpec &l = kLayers[i];
+        const Step &st = kSteps[step_of_layer(i)];
+        const QpBuf &in = t.fwd.buf[st.src], &out = t.fwd.buf[st.dst];
+        const int ih = in.Hb - 2 * in.pad, iw = in.Wb - 2 * in.pad, oh = out.Hb - 2 * out.pad, ow = out.Wb - 2 * out.pad;
+        const int ci = lcin(l, f), co = lcout(l, f);
+        size_t e = 0, p = 0;
+        if (l.kind == ND_CONV3) {          // A = g(out) on the input grid
+            e = (size_t)(co / 4) * B * in.Hb * in.Wb;
+            p = nd_wgrad_partial_floats(9, co, ci, (long)B * in.Hb * in.Wb, nullptr, nullptr);
+        } else if (l.kind == ND_CONVT3) {  // A = input interior on the output grid
+            e = (size_t)((ci + 3) / 4) * B * oh * ow;
+            p = nd_wgrad_partial_floats(9, ci, co, (long)B * oh * ow, nullptr, nullptr);
+        } else {                           // up: B = one phase of g(out) on the input grid
+            e = (size_t)(co / 4) * B * ih * iw;
+            p = nd_wgrad_partial_floats(1, ci, co, (long)B * ih * iw, nullptr, nullptr);
+        }
+        if (e > scratch_elems) scratch_elems = e;
+        if (p > pf) pf = p;
+    }
+    t.scratch = QpBuf();
+    t.scratch.base = (float *)(base ? base + off : nullptr);
+    off += (scratch_elems + 4096) * 16;
+    off = (off + 255) & ~(size_t)255;
+    t.partial = (float *)(base ? base + off : nullptr);
+    t.partial_floats = pf;
+    off += pf * 4;
+    off = (off + 255) & ~(size_t)255;
+    t.red = (float *)(base ? base + off : nullptr);
+    off += kRedFloats * 4;
+    t.gy = (float *)(base ? base + off : nullptr);
+    off += (size_t)B * 3 * cs * cs * 4;
+    off = (off + 255) & ~(size_t)255;
+    t.bytes = off;
+    return t;
+}
+
+QpBuf scratch_view(const TrainPlan &t, int planes, int B, int H, int W) {
+    QpBuf q = t.scratch;
+    q.planes = planes;
+    q.B = B;
+    q.Hb = H;
+    q.Wb = W;
+    q.pad = 0;
+    q.dt = ND_F32;
+    q.pstride = (long)B * H * W;
+    return q;
+}
+
+int check_train(int funit, int cs, int batch) {
+    if (funit < 8 || funit % 8) ND_FAIL(ND_EINVAL, "UtNet training: funit=%d must be a positive multiple of 8", funit);
+    if (!valid_cs(cs)) ND_FAIL(ND_EINVAL, "UtNet training: crop size %d is not of the form 16k+56 (e.g. 136, 184)", cs);
+    if (batch <= 0) ND_FAIL(ND_EINVAL, "UtNet training: batch=%d", batch);
+    return ND_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ C ABI
+extern "C" size_t nd_utnet_param_count(int funit) { return (funit < 8 || funit % 8) ? 0 : param_layout(funit).total; }
+extern "C" int nd_utnet_param_range(int funit, int tensor_idx, size_t *offset, size_t *count) {
+    if (funit < 8 || funit % 8) ND_FAIL(ND_EINVAL, "bad funit");
+    const ParamLayout pl = param_layout(funit);
+    if (tensor_idx < 0 || tensor_idx >= (int)pl.off.size()) ND_FAIL(ND_EINVAL, "tensor index %d out of range", tensor_idx);
+    if (offset) *offset = pl.off[tensor_idx];
+    if (count) *count = pl.cnt[tensor_idx];
+    return ND_OK;
+}
+extern "C" size_t nd_utnet_train_blob_bytes(int funit) {
+    if (funit < 8 || funit % 8) return 0;
+    return (blob_layout(funit, ND_F32).total + bwd_blob_layout(funit).total) * sizeof(float);
+}
+extern "C" size_t nd_utnet_train_workspace_bytes(int funit, int cs, int batch) {
+    if (check_train(funit, cs, batch) != ND_OK) return 0;
+    return make_train_plan(funit, cs, batch, nullptr).bytes;
+}
+extern "C" int nd_utnet_train_workspace_init(void *ws, size_t ws_bytes, int funit, int cs, int batch, void *stream) {
+    ND_TRY(check_train(funit, cs, batch));
+    const size_t need = make_train_plan(funit, cs, batch, nullptr).bytes;
+    if (!ws || ws_bytes < need) ND_FAIL(ND_ENOMEM, "UtNet training workspace: %zu B given, %zu B needed", ws_bytes, need);
+    ND_HIP(hipMemsetAsync(ws, 0, need, (hipStream_t)stream));   // zero borders of activations AND gradients, slack
+    return ND_OK;
+}
+
+// One training step without the optimizer: packs the weights on the device, runs forward (PReLU only), the loss
+//   loss = w_l1 * mean|clip(y,0,1) - target| + w_mse * mean (clip(y,0,1) - target)^2
+// and the backward pass.  params / grads: flat fp32 buffers in state-dict order (nd_utnet_param_range);
+// x, target, y_out: [batch,3,cs,cs] NCHW fp32; loss_out: one float in HBM; blobs: nd_utnet_train_blob_bytes scratch.
+extern "C" int nd_utnet_train_step(int funit, const float *params, float *grads, void *blobs, const float *x,
+                                   const float *target, float *y_out, float w_l1, float w_mse, float *loss_out, int batch,
+                                   int cs, void *ws, size_t ws_bytes, void *stream) {
+    ND_TRY(check_train(funit, cs, batch));
+    if (!params || !grads || !blobs || !x || !target || !y_out || !loss_out || !ws) ND_FAIL(ND_EINVAL, "train step: null pointer");
+    TrainPlan t = make_train_plan(funit, cs, batch, (char *)ws);
+    if (ws_bytes < t.bytes) ND_FAIL(ND_ENOMEM, "UtNet training workspace: %zu B given, %zu B needed", ws_bytes, t.bytes);
+    hipStream_t s = (hipStream_t)stream;
+    const int f = funit, B = batch;
+    const ParamLayout pl = param_layout(f);
+    const BlobLayout bl = blob_layout(f, ND_F32);
+    const BwdBlob bb = bwd_blob_layout(f);
+    float *fblob = (float *)blobs;
+    float *bblob = fblob + bl.total;
+    auto P = [&](const std::string &name) -> const float * { return params + pl.off[tensor_index(name)]; };
+    auto G = [&](const std::string &name) -> float * { return grads + pl.off[tensor_index(name)]; };
+
+    // ---- 1. pack weights on the device (forward roles, and transposed roles for the data gradients)
+    const float *slopes[kNumSlopes] = {};
+    for (int i = 0; i < kNumLayers; ++i) {
+        const LayerSpec &l = kLayers[i];
+        const int ci = lcin(l, f), co = lcout(l, f);
+        const float *w = P(std::string(l.key) + ".weight"), *b = P(std::string(l.key) + ".bias");
+        if (l.prelu >= 0) slopes[l.prelu] = P(prelu_name(l.key));
+        if (l.kind == ND_CONV1) {
+            ND_HIP(hipMemcpyAsync(fblob + bl.off[i], w, sizeof(float) * 3 * ci, hipMemcpyDeviceToDevice, s));
+            ND_HIP(hipMemcpyAsync(fblob + bl.off[i] + 3 * ci, b, sizeof(float) * 3, hipMemcpyDeviceToDevice, s));
+            continue;
+        }
+        {
+            const int MT = nd_mtiles(l.kind, co), KB = nd_kblocks(ci), taps = nd_taps(l.kind);
+            const long nw = (long)MT * KB * taps * 256;
+            const int M = l.kind == ND_CONVT2S2 ? 4 * co : co;
+            hipLaunchKernelGGL(k_pack_dev, dim3((unsigned)((nw + MT * 32 + 255) / 256)), dim3(256), 0, s, l.kind, ci, co, M, KB,
+                               taps, w, b, fblob + bl.off[i], nw, MT * 32);
+        }
+        if (i > 0) {   // transposed role: cin' = co, cout' = ci, no bias
+            const int kt = transposed_kind(l.kind);
+            const int MT = nd_mtiles(kt, ci), KB = nd_kblocks(co), taps = nd_taps(kt);
+            const long nw = (long)MT * KB * taps * 256;
+            hipLaunchKernelGGL(k_pack_dev, dim3((unsigned)((nw + MT * 32 + 255) / 256)), dim3(256), 0, s, kt, co, ci, ci, KB, taps,
+                               w, (const float *)nullptr, bblob + bb.off[i], nw, MT * 32);
+        }
+    }
+    ND_HIP(hipGetLastError());
+    // slope table of the forward blob header
+    for (int k = 0; k < kNumSlopes; ++k)
+        ND_HIP(hipMemcpyAsync(fblob + k, slopes[k], sizeof(float), hipMemcpyDeviceToDevice, s));
+
+    // ---- 2. forward (training mode: pre-activations kept)
+    ND_TRY(nd_launch_reflect_pack(x, B, cs, cs, t.fwd.buf[X0], s));
+    ND_TRY(run_stack(f, ND_ACT_PRELU, ND_F32, fblob, t.fwd, s, nullptr, t.pre));
+    const float *fw = fblob + bl.off[kNumLayers - 1];
+    ND_TRY(nd_launch_final1x1(t.fwd.buf[T4B], f, fw, fw + 3 * f, 2, y_out, cs, cs, s));
+
+    // ---- 3. loss and its gradient
+    const long nout = (long)B * 3 * cs * cs;
+    const int lblocks = 1024;
+    hipLaunchKernelGGL(k_loss_grad, dim3(lblocks), dim3(256), 0, s, (const float *)y_out, target, nout, w_l1, w_mse, t.gy, t.red);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, (const float *)t.red, lblocks, 1.f / (float)nout, loss_out);
+    ND_HIP(hipGetLastError());
+
+    // ---- 4. backward
+    // final 1x1
+    {
+        const QpBuf &a = t.fwd.buf[T4B], &g = t.g[T4B];
+        hipLaunchKernelGGL(k_final_wgrad, dim3(3, f / 4), dim3(256), 0, s, (const float *)t.gy, cs, (const f32x4 *)a.base, a.np(),
+                           a.Hb, a.Wb, 2, B, f, G("tconvs4.4.weight"), G("tconvs4.4.bias"));
+        dim3 grid((g.Wb + 127) / 128, g.Hb, B * (f / 4));
+        hipLaunchKernelGGL(k_final_bwd_data, grid, dim3(128), 0, s, (const float *)t.gy, cs, fw, f, 2, (f32x4 *)g.base, g.np(), g.Hb,
+                           g.Wb, B);
+        ND_HIP(hipGetLastError());
+    }
+    for (int si = kNumSteps - 1; si >= 0; --si) {
+        const Step &st = kSteps[si];
+        if (st.layer < 0) {
+            // pool: the skip half of the concat buffer was pooled into P; route g(P) back and ADD it to g(skip)
+            const int planes = st.dst_plane0_mul * f / 4, plane0 = planes;
+            const QpBuf &gp = t.g[st.dst], &fw_ = t.fwd.buf[st.src], &gc = t.g[st.src];
+            const int Ho = gp.Hb - 2 * gp.pad, Wo = gp.Wb - 2 * gp.pad;
+            dim3 grid((Wo + 127) / 128, Ho, B * planes);
+            hipLaunchKernelGGL(k_maxpool_bwd_add, grid, dim3(128), 0, s, (const f32x4 *)gp.base, gp.np(), gp.Hb, gp.Wb, gp.pad,
+                               (const f32x4 *)fw_.base + (long)plane0 * fw_.np(), fw_.np(), fw_.Hb, fw_.Wb, fw_.pad,
+                               (f32x4 *)gc.base + (long)plane0 * gc.np(), gc.np(), gc.Hb, gc.Wb, gc.pad, Ho, Wo, B);
+            ND_HIP(hipGetLastError());
+            continue;
+        }
+        const LayerSpec &l = kLayers[st.layer];
+        const int ci = lcin(l, f), co = lcout(l, f);
+        const QpBuf &in = t.fwd.buf[st.src];    // layer input (forward values)
+        const QpBuf &go = t.g[st.dst];          // gradient of the layer's output buffer
+        const int oplane0 = st.dst_plane0_mul * f / 4, oplanes = co / 4;
+        const int oh = go.Hb - 2 * go.pad, ow = go.Wb - 2 * go.pad;
+        const int ih = in.Hb - 2 * in.pad, iw = in.Wb - 2 * in.pad;
+        // activation backward (in place) + slope gradient
+        if (l.prelu >= 0) {
+            const QpBuf &pr = t.pre[l.prelu];
+            hipLaunchKernelGGL(k_prelu_bwd, dim3(B, oplanes), dim3(256), 0, s, (f32x4 *)go.base + (long)oplane0 * go.np(), go.np(),
+                               go.Hb, go.Wb, go.pad, (const f32x4 *)pr.base, pr.np(), oh, ow, slopes[l.prelu], t.red);
+            hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, (const float *)t.red, B * oplanes, 1.f, G(prelu_name(l.key)));
+            ND_HIP(hipGetLastError());
+        }
+        // bias gradient
+        ND_TRY(nd_launch_channel_sum(go, oplane0, co, G(std::string(l.key) + ".bias"), s));
+        // weight gradient
+        float *dw = G(std::string(l.key) + ".weight");
+        if (l.kind == ND_CONV3) {
+            QpBuf a = scratch_view(t, oplanes, B, in.Hb, in.Wb);
+            ND_TRY(nd_launch_repitch(go, oplane0, oplanes, 1, 0, 0, a, 0, 0, oh, ow, s));
+            ND_TRY(nd_launch_wgrad(a, 0, co, in, 0, ci, 9, 9, 0, t.partial, t.partial_floats, dw, s));
+        } else if (l.kind == ND_CONVT3) {
+            QpBuf a = scratch_view(t, (ci + 3) / 4, B, oh, ow);
+            ND_TRY(nd_launch_repitch(in, 0, (ci + 3) / 4, 1, 0, 0, a, 0, 0, ih, iw, s));
+            QpBuf gb = go;   // pad 0 by construction: the whole buffer is the grid
+            ND_TRY(nd_launch_wgrad(a, 0, ci, gb, oplane0, co, 9, 9, 0, t.partial, t.partial_floats, dw, s));
+        } else {   // ConvTranspose2d(2, s=2): four 1-tap problems on the input grid
+            for (int ab = 0; ab < 4; ++ab) {
+                QpBuf bq = scratch_view(t, oplanes, B, ih, iw);
+                ND_TRY(nd_launch_repitch(go, oplane0, oplanes, 2, ab >> 1, ab & 1, bq, 0, 0, ih, iw, s));
+                ND_TRY(nd_launch_wgrad(in, 0, ci, bq, 0, co, 1, 4, ab, t.partial, t.partial_floats, dw, s));
+            }
+        }
+        // data gradient into g(input buffer): a forward launch of the transposed kind
+        if (st.layer > 0) {
+            ConvDesc d;
+            d.kind = transposed_kind(l.kind);
+            d.act = ND_ACT_NONE;
+            d.slope = 1.f;
+            d.slope_dev = nullptr;
+            d.cin = co;
+            d.cout = ci;
+            d.wpk = bblob + bb.off[st.layer];
+            d.bias = d.wpk + (size_t)nd_mtiles(d.kind, ci) * nd_kblocks(co) * nd_taps(d.kind) * 256;
+            d.in = go;
+            d.in_plane0 = oplane0;
+            d.out = t.g[st.src];
+            d.out_plane0 = 0;
+            d.variant = -1;
+            ND_TRY(nd_launch_conv(d, s));
+        }
+    }
+    return ND_OK;
+}
+
+// torch.optim.Adam(params, lr, betas=(b1,b2), eps, amsgrad) on flat buffers; step = 1, 2, ...
+extern "C" int nd_adam_step(float *params, const float *grads, float *m, float *v, float *vmax, size_t n, float lr, float b1,
+                            float b2, float eps, int step, int amsgrad, void *stream) {
+    if (!params || !grads || !m || !v || (amsgrad && !vmax) || step < 1) ND_FAIL(ND_EINVAL, "nd_adam_step: bad arguments");
+    const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, vmax,
+                       (long)n, lr, b1, b2, eps, bc1, bc2, amsgrad);
+    ND_HIP(hipGetLastError());
+    return ND_OK;
+}
