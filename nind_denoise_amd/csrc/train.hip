@@ -11,19 +11,16 @@ int nd_launch_wgrad(const QpBuf &A, int a_plane0, int M, const QpBuf &Bq, int b_
                     int tap0, float *partial, size_t partial_floats, float *dw, hipStream_t s);
 
 // ------------------------------------------------------------------ per-channel sum over all pixels (bias gradient)
-// one workgroup per plane; fixed summation order (deterministic)
-__global__ __launch_bounds__(256) void k_channel_sum(const f32x4 *__restrict__ src, long np, int B, int Hb, int Wb, int pad,
-                                                     int H, int W, int C, float *__restrict__ out) {
+// two stages, fixed summation order (deterministic): one workgroup per (plane, image), then one per plane
+__global__ __launch_bounds__(256) void k_channel_sum1(const f32x4 *__restrict__ src, long np, int Hb, int Wb, int pad, int H,
+                                                      int W, f32x4 *__restrict__ partial) {
     __shared__ f32x4 red[256];
-    const int q = blockIdx.x;
-    const f32x4 *s = src + (long)q * np;
+    const int q = blockIdx.x, b = blockIdx.y;
+    const f32x4 *s = src + (long)q * np + (long)b * Hb * Wb;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const long total = (long)B * H * W;
-    for (long i = threadIdx.x; i < total; i += 256) {
-        const int b = (int)(i / ((long)H * W));
-        const int r = (int)(i - (long)b * H * W);
-        const int y = r / W, x = r - y * W;
-        acc += s[((long)b * Hb + y + pad) * Wb + x + pad];
+    for (int i = threadIdx.x; i < H * W; i += 256) {
+        const int y = i / W, x = i - y * W;
+        acc += s[(long)(y + pad) * Wb + x + pad];
     }
     red[threadIdx.x] = acc;
     __syncthreads();
@@ -31,13 +28,22 @@ __global__ __launch_bounds__(256) void k_channel_sum(const f32x4 *__restrict__ s
         if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
         __syncthreads();
     }
-    if (threadIdx.x < 4 && 4 * q + (int)threadIdx.x < C) out[4 * q + threadIdx.x] = red[0][threadIdx.x];
+    if (threadIdx.x == 0) partial[(long)q * gridDim.y + b] = red[0];
+}
+__global__ __launch_bounds__(64) void k_channel_sum2(const f32x4 *__restrict__ partial, int B, int C, float *__restrict__ out) {
+    const int q = blockIdx.x;
+    if (threadIdx.x >= 4 || 4 * q + (int)threadIdx.x >= C) return;
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) acc += partial[(long)q * B + b][threadIdx.x];
+    out[4 * q + threadIdx.x] = acc;
 }
 
-int nd_launch_channel_sum(const QpBuf &src, int plane0, int C, float *out, hipStream_t s) {
-    const int H = src.Hb - 2 * src.pad, W = src.Wb - 2 * src.pad;
-    hipLaunchKernelGGL(k_channel_sum, dim3((C + 3) / 4), dim3(256), 0, s, (const f32x4 *)src.base + (long)plane0 * src.np(),
-                       src.np(), src.B, src.Hb, src.Wb, src.pad, H, W, C, out);
+// scratch: at least 4 * ceil(C/4) * B floats
+int nd_launch_channel_sum(const QpBuf &src, int plane0, int C, float *out, float *scratch, hipStream_t s) {
+    const int H = src.Hb - 2 * src.pad, W = src.Wb - 2 * src.pad, planes = (C + 3) / 4;
+    hipLaunchKernelGGL(k_channel_sum1, dim3(planes, src.B), dim3(256), 0, s, (const f32x4 *)src.base + (long)plane0 * src.np(),
+                       src.np(), src.Hb, src.Wb, src.pad, H, W, (f32x4 *)scratch);
+    hipLaunchKernelGGL(k_channel_sum2, dim3(planes), dim3(64), 0, s, (const f32x4 *)scratch, src.B, C, out);
     ND_HIP(hipGetLastError());
     return ND_OK;
 }
@@ -93,7 +99,7 @@ WgPlan wg_plan(int kind, int B, int cin, int cout, int h, int w, char *base) {
     }
     p.partial_floats = nd_wgrad_partial_floats(p.taps, p.M, p.N, (long)B * p.gh * p.gw, nullptr, nullptr);
     p.partial = (float *)(base ? base + off : nullptr);
-    off += p.partial_floats * 4;
+    off += p.partial_floats * 4 + (size_t)4 * yp * B * 4 + 256;   // + channel-sum scratch behind the partial sums
     p.bytes = off;
     return p;
 }
@@ -117,7 +123,7 @@ extern "C" int nd_layer_wgrad(int kind, const float *x, const float *dy, int bat
     ND_HIP(hipMemsetAsync(ws, 0, need, s));
     ND_TRY(nd_launch_nchw_to_qp(x, cin, p.x, 0, s));
     ND_TRY(nd_launch_nchw_to_qp(dy, cout, p.dy, 0, s));
-    if (db) ND_TRY(nd_launch_channel_sum(p.dy, 0, cout, db, s));
+    if (db) ND_TRY(nd_launch_channel_sum(p.dy, 0, cout, db, p.partial + p.partial_floats, s));
     if (kind == ND_CONV3 || kind == ND_CONV1) {
         ND_TRY(nd_launch_repitch(p.dy, 0, p.dy.planes, 1, 0, 0, p.a, 0, 0, p.dy.Hb, p.dy.Wb, s));
         ND_TRY(nd_launch_wgrad(p.a, 0, p.M, p.b, 0, p.N, p.taps, p.taps, 0, p.partial, p.partial_floats, dw, s));

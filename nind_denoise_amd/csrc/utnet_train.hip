@@ -22,7 +22,7 @@ int nd_launch_repitch(const QpBuf &src, int src_plane0, int planes, int ss, int 
 size_t nd_wgrad_partial_floats(int taps, int M, int N, long K, int *ksplit_out, int *cps_out);
 int nd_launch_wgrad(const QpBuf &A, int a_plane0, int M, const QpBuf &Bq, int b_plane0, int N, int taps, int taps_total,
                     int tap0, float *partial, size_t partial_floats, float *dw, hipStream_t s);
-int nd_launch_channel_sum(const QpBuf &src, int plane0, int C, float *out, hipStream_t s);
+int nd_launch_channel_sum(const QpBuf &src, int plane0, int C, float *out, float *scratch, hipStream_t s);
 
 // ------------------------------------------------------------------ elementwise kernels
 // g (interior of a bordered gradient buffer, planes [plane0, plane0+planes)) *= prelu'(pre);  partial[block] = sum g*pre over pre <= 0
@@ -148,20 +148,16 @@ __global__ void k_final_bwd_data(const float *__restrict__ gy, int S, const floa
     g[(long)q * gnp + ((long)b * Hb + Y) * Wb + X] = o;
 }
 
-// weight / bias gradient of the final 1x1: one workgroup per (co, plane); dw[co][4q..4q+3], db[co] (plane 0 only)
-__global__ __launch_bounds__(256) void k_final_wgrad(const float *__restrict__ gy, int S, const f32x4 *__restrict__ act, long anp,
-                                                     int Hb, int Wb, int crop, int B, int cin, float *__restrict__ dw,
-                                                     float *__restrict__ db) {
+// weight / bias gradient of the final 1x1, stage 1: one workgroup per (co, plane, image) -> partial[(co*planes+q)*B + b] (x,y,z,w = dw, then db)
+__global__ __launch_bounds__(256) void k_final_wgrad1(const float *__restrict__ gy, int S, const f32x4 *__restrict__ act, long anp,
+                                                      int Hb, int Wb, int crop, f32x4 *__restrict__ pw, float *__restrict__ pb) {
     __shared__ f32x4 red[256];
     __shared__ float redb[256];
-    const int co = blockIdx.x, q = blockIdx.y;
+    const int co = blockIdx.x, q = blockIdx.y, b = blockIdx.z;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float accb = 0.f;
-    const long total = (long)B * S * S;
-    for (long i = threadIdx.x; i < total; i += 256) {
-        const int b = (int)(i / ((long)S * S));
-        const int r = (int)(i - (long)b * S * S);
-        const int y = r / S, x = r - y * S;
+    for (int i = threadIdx.x; i < S * S; i += 256) {
+        const int y = i / S, x = i - y * S;
         const float gv = gy[(((long)b * 3 + co) * S + y) * S + x];
         acc += act[(long)q * anp + ((long)b * Hb + y + crop) * Wb + x + crop] * gv;
         accb += gv;
@@ -176,8 +172,26 @@ __global__ __launch_bounds__(256) void k_final_wgrad(const float *__restrict__ g
         }
         __syncthreads();
     }
-    if (threadIdx.x < 4 && 4 * q + (int)threadIdx.x < cin) dw[(long)co * cin + 4 * q + threadIdx.x] = red[0][threadIdx.x];
-    if (threadIdx.x == 0 && q == 0) db[co] = redb[0];
+    if (threadIdx.x == 0) {
+        const long o = ((long)co * gridDim.y + q) * gridDim.z + b;
+        pw[o] = red[0];
+        pb[o] = redb[0];
+    }
+}
+__global__ __launch_bounds__(64) void k_final_wgrad2(const f32x4 *__restrict__ pw, const float *__restrict__ pb, int planes, int B,
+                                                     int cin, float *__restrict__ dw, float *__restrict__ db) {
+    const int co = blockIdx.x, q = blockIdx.y;
+    const long o = ((long)co * planes + q) * B;
+    if (threadIdx.x < 4 && 4 * q + (int)threadIdx.x < cin) {
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) acc += pw[o + b][threadIdx.x];
+        dw[(long)co * cin + 4 * q + threadIdx.x] = acc;
+    }
+    if (threadIdx.x == 4 && q == 0) {
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) acc += pb[o + b];
+        db[co] = acc;
+    }
 }
 
 // device-side weight packing (same map as pack.hip's host packer, fp32): nw packed weights followed by MT*32 biases
@@ -296,7 +310,7 @@ struct TrainPlan {
     float *gy;              // d loss / d output  [B,3,S,S]
     size_t bytes;
 };
-constexpr int kRedFloats = 1 << 16;
+constexpr int kRedFloats = 1 << 19;   // reduction scratch: >= 4 floats x planes x batch
 
 int step_of_layer(int layer) {
     for (int i = 0; i < kNumSteps; ++i)
@@ -499,8 +513,12 @@ extern "C" int nd_utnet_train_step(int funit, const float *params, float *grads,
     // final 1x1
     {
         const QpBuf &a = t.fwd.buf[T4B], &g = t.g[T4B];
-        hipLaunchKernelGGL(k_final_wgrad, dim3(3, f / 4), dim3(256), 0, s, (const float *)t.gy, cs, (const f32x4 *)a.base, a.np(),
-                           a.Hb, a.Wb, 2, B, f, G("tconvs4.4.weight"), G("tconvs4.4.bias"));
+        f32x4 *pw = (f32x4 *)t.red;
+        float *pb = t.red + (size_t)4 * 3 * (f / 4) * B;
+        hipLaunchKernelGGL(k_final_wgrad1, dim3(3, f / 4, B), dim3(256), 0, s, (const float *)t.gy, cs, (const f32x4 *)a.base,
+                           a.np(), a.Hb, a.Wb, 2, pw, pb);
+        hipLaunchKernelGGL(k_final_wgrad2, dim3(3, f / 4), dim3(64), 0, s, (const f32x4 *)pw, (const float *)pb, f / 4, B, f,
+                           G("tconvs4.4.weight"), G("tconvs4.4.bias"));
         dim3 grid((g.Wb + 127) / 128, g.Hb, B * (f / 4));
         hipLaunchKernelGGL(k_final_bwd_data, grid, dim3(128), 0, s, (const float *)t.gy, cs, fw, f, 2, (f32x4 *)g.base, g.np(), g.Hb,
                            g.Wb, B);
@@ -536,7 +554,7 @@ extern "C" int nd_utnet_train_step(int funit, const float *params, float *grads,
             ND_HIP(hipGetLastError());
         }
         // bias gradient
-        ND_TRY(nd_launch_channel_sum(go, oplane0, co, G(std::string(l.key) + ".bias"), s));
+        ND_TRY(nd_launch_channel_sum(go, oplane0, co, G(std::string(l.key) + ".bias"), t.red, s));
         // weight gradient
         float *dw = G(std::string(l.key) + ".weight");
         if (l.kind == ND_CONV3) {

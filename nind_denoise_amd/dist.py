@@ -125,3 +125,15 @@ def denoise_frame_sharded(compute, frame, canvas, geo, group=None, root=0):
     compute(frame, canvas, lo, hi)
     gather_canvas(canvas, geo, group, root)
     return canvas
+
+
+def average_gradients(flat, group=None):
+    """Data-parallel training (BASELINE config 5): ONE all-reduce of the flat state-dict-order gradient buffer
+    (124 MB fp32 for UtNet(64)), then the mean.  No-op without an initialised process group."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return flat
+    world = dist.get_world_size(group)
+    if world > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.div_(world)
+    return flat

@@ -12,9 +12,9 @@ buffer with the same layout, so the data-parallel reduction is one all-reduce an
 import ctypes
 
 import torch
-import torch.distributed as dist
 
 from . import _lib
+from .dist import average_gradients
 from .networks.UtNet import UtNet, valid_cs
 
 
@@ -90,9 +90,7 @@ class UtNetTrainer:
                                                     float(self.weights.get("L1", 0.0)), float(self.weights.get("MSE", 0.0)),
                                                     self.loss.data_ptr(), batch, cs, ws.data_ptr(), ws.numel(),
                                                     _lib.stream_ptr(self.device)), "nd_utnet_train_step")
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self.group)     # RCCL: one flat 124 MB reduction
-            self.grads.div_(dist.get_world_size(self.group))
+        average_gradients(self.grads, self.group)     # RCCL: one flat all-reduce (124 MB for UtNet(64))
         return y, self.loss
 
     def optimizer_step(self):

@@ -84,3 +84,32 @@ def test_shard_geometry_covers_every_tile_once():
             y0, y1 = geo.rows_in(a, b)
             o0, o1 = geo.rows_out(a, b)
             assert 0 <= y0 <= o0 < o1 <= y1 <= 4000
+
+
+def _grad_worker(rank, world, port, outq):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nind_denoise_amd import dist as ndist
+        flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+        ndist.average_gradients(flat)
+        outq.put((rank, flat.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_gradient_average_world_3():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(3))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = np.arange(1000, dtype=np.float32) * 2.0      # mean of 1x, 2x, 3x
+    for r in range(3):
+        assert np.array_equal(got[r], want)
