@@ -192,6 +192,11 @@ int nd_conv_bench(int kind, int dtype, int batch, int cin, int cout, int h, int 
 int nd_num_conv_variants(void);
 const char *nd_conv_variant_name(int variant);
 
+/* Split-K tail (on by default): the tiles of a launch's last, partial round of workgroups are cut along K so that the
+ * idle CUs share them; the slices are added in a fixed order (deterministic), but the fp32 summation order differs from
+ * the unsplit launch in the last bits.  Returns the previous setting.  Measurement switch; not needed for correctness. */
+int nd_conv_split_enable(int on);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,8 @@ static int tile_span(const Variant &V, const QpBuf &in, bool cross) {
     // consecutive valid pixels are s input pixels apart; every row end adds s*(Wb - Wv), every image end the rest of the image
     int span = s * n + s * (in.Wb - Wv) * ((n - 1) / Wv + 1);
     if (cross) span += (in.Hb * in.Wb - Hv * s * in.Wb) * ((n - 1) / (Hv * Wv) + 1);
+    const long whole = (long)in.B * in.Hb * in.Wb;   // a tile never reads past the pixels in use (tiny images: 3x3 at the bottom)
+    if (cross && span > whole) span = (int)whole;
     span += taps == 9 ? 2 * in.Wb + 2 : (taps == 4 ? in.Wb + 1 : 0);
     return span;
 }
@@ -61,7 +63,104 @@ static size_t variant_lds(const Variant &V, const QpBuf &in, bool *cross_out = n
 
 static const size_t kMaxLds = 160 * 1024;
 
+// ------------------------------------------------------------------ split-K tail
+// Persistent workgroups finish whole rounds of tiles at full rate, but the last, partial round leaves CUs idle (and a layer
+// with fewer tiles than CUs -- the deep levels of a small batch -- is nothing but a partial round).  The tiles of that
+// round are therefore cut along K into S slices that fill the idle CUs; slices store raw accumulators and this kernel adds
+// them in slice order (deterministic), then applies bias / activation exactly like the conv epilogue.
+// grid: (split tiles, MBLK/4 channel quads)
+__global__ __launch_bounds__(256) void k_split_finish(ConvParams p, int mblk, int nblk, int up, int dt) {
+    const int t = blockIdx.x, quad = blockIdx.y;
+    const int id = p.split_first + t;
+    const int nb = id / p.n_tiles_m, mb = id - nb * p.n_tiles_m;
+    const int m4 = mb * mblk + quad * 4;
+    if (m4 >= p.M) return;
+    const float slope = p.act == ND_ACT_NONE ? 1.f : (p.slope_dev ? *p.slope_dev : p.slope);
+    const f32x4 bv = *(const f32x4 *)(p.bias + m4);
+    const int nq = mblk / 4;
+    for (int l = threadIdx.x; l < nblk; l += 256) {
+        int bi, r;
+        if (p.tpi) {
+            bi = nb / p.tpi;
+            r = (nb - bi * p.tpi) * nblk + l;
+            if (r >= p.PV) continue;
+        } else {
+            const long g = (long)nb * nblk + l;
+            if (g >= (long)p.nimg * p.PV) continue;
+            bi = (int)(g / p.PV);
+            r = (int)(g - (long)bi * p.PV);
+        }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < p.S; ++ks) acc += p.part[((size_t)(t * p.S + ks) * nq + quad) * nblk + l];
+        acc += bv;
+        if (p.pre) p.pre[(long)(m4 >> 2) * p.pre_plane + (long)bi * p.PV + r] = acc;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = p.act <= ND_ACT_PRELU ? (acc[e] > 0.f ? acc[e] : acc[e] * slope) : apply_act(acc[e], p.act, slope);
+        const int y = r / p.Wv, x = r - y * p.Wv;
+        int co = m4;
+        long pix;
+        if (up) {
+            const int ab = m4 / p.cout;
+            co = m4 - ab * p.cout;
+            pix = (long)bi * p.Po + (long)(2 * y + p.opad + (ab >> 1)) * p.Wo + (2 * x + p.opad + (ab & 1));
+        } else {
+            pix = (long)bi * p.Po + (long)(y + p.opad) * p.Wo + (x + p.opad);
+        }
+        if (dt == ND_F32) {
+            p.out[(long)(p.out_plane0 + (co >> 2)) * p.out_plane + pix] = v;
+        } else {
+            char *dst = (char *)p.out + (((long)(p.out_plane0 + (co >> 3)) * p.out_plane + pix) << 4) + ((co >> 2) & 1) * 8;
+            if (dt == ND_BF16) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+                *(bf16x4 *)dst = o;
+            } else {
+                f16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
+                *(f16x4 *)dst = o;
+            }
+        }
+    }
+}
+
+// Time of a launch in units of "one workgroup runs one K chunk": `slots` workgroups run concurrently, `ntiles` tiles of
+// `nchunks` chunks each.  Picks the split of the partial round (S slices of cps chunks) that minimises it; kOver chunks
+// of fixed cost per work item (pipeline prologue, epilogue / partial store + its share of k_split_finish).
+struct SplitPlan { int first, S, cps; double time; };
+static SplitPlan plan_split(long ntiles, int nchunks, long slots, long max_items, double over) {
+    SplitPlan b;
+    const long full = ntiles / slots * slots, R = ntiles - full;
+    b.first = (int)ntiles;
+    b.S = 1;
+    b.cps = nchunks;
+    b.time = (double)((ntiles + slots - 1) / slots) * (nchunks + over);
+    if (R == 0 || max_items <= 0) return b;
+    const double base = (double)(full / slots) * (nchunks + over);
+    for (int S = 2; S <= nchunks && S <= 64; ++S) {
+        const int cps = (nchunks + S - 1) / S, Se = (nchunks + cps - 1) / cps;
+        if (R * Se > max_items) break;
+        const double t = base + (double)((R * Se + slots - 1) / slots) * (cps + 1.5 * over);
+        if (t < 0.93 * b.time) {
+            b.first = (int)full;
+            b.S = Se;
+            b.cps = cps;
+            b.time = t;
+        }
+    }
+    return b;
+}
+
 static int g_num_cus = 0;
+static const double kSplitOver = 3.0;
+static int g_split_on = 1;
+extern "C" int nd_conv_split_enable(int on) {
+    const int was = g_split_on;
+    g_split_on = on ? 1 : 0;
+    return was;
+}
 
 static int pick_variant(const ConvDesc &d, int M) {
     const int taps = nd_taps(d.kind);
@@ -87,7 +186,8 @@ static int pick_variant(const ConvDesc &d, int M) {
                 const long pv = (long)Hv * Wv;
                 const long tn = cross ? ((long)d.in.B * pv + V.nblk - 1) / V.nblk : ((pv + V.nblk - 1) / V.nblk) * d.in.B;
                 const long tiles = tn * ((M + V.mblk - 1) / V.mblk);
-                const double cost = (double)((tiles + cus - 1) / cus) * V.nblk * c.unit;
+                const long cap = d.part && g_split_on ? (long)(d.part_bytes / ((size_t)V.mblk * V.nblk * 4)) : 0;
+                const double cost = plan_split(tiles, KB / V.kbc, cus, cap, kSplitOver).time * V.nblk * c.unit;
                 if (best_v < 0 || cost < best) {
                     best = cost;
                     best_v = c.v;
@@ -196,8 +296,19 @@ int nd_launch_conv(const ConvDesc &d, hipStream_t stream) {
     p.n_tiles_m = (M + V.mblk - 1) / V.mblk;
     const long ntiles = (long)p.n_tiles_n * p.n_tiles_m;
     const int per_cu = lds * 2 <= kMaxLds && V.threads <= 256 ? 2 : 1;
-    const long grid = ntiles < (long)g_num_cus * per_cu ? ntiles : (long)g_num_cus * per_cu;
+    const long slots = (long)g_num_cus * per_cu;
+    const long cap = d.part && g_split_on ? (long)(d.part_bytes / ((size_t)V.mblk * V.nblk * 4)) : 0;
+    const SplitPlan sp = plan_split(ntiles, KB / V.kbc, slots, cap, kSplitOver);
+    p.split_first = sp.first;
+    p.S = sp.S;
+    p.cps = sp.cps;
+    p.nitems = (int)(sp.first + (ntiles - sp.first) * sp.S);
+    p.part = (f32x4 *)d.part;
+    const long grid = p.nitems < slots ? p.nitems : slots;
     hipLaunchKernelGGL(V.fn, dim3((unsigned)grid), dim3(V.threads), lds, stream, p);
+    if (sp.first < ntiles)
+        hipLaunchKernelGGL(k_split_finish, dim3((unsigned)(ntiles - sp.first), V.mblk / 4), dim3(256), 0, stream, p, V.mblk,
+                           V.nblk, up ? 1 : 0, dt);
     ND_HIP(hipGetLastError());
     return ND_OK;
 }

@@ -63,7 +63,11 @@ struct ConvDesc {
     int in_plane0 = 0;  // first input plane inside `in` (a channel slice of a concat / gradient buffer)
     float *pre = nullptr;   // training: also store the pre-activation (acc + bias), compact [C/4][B][Hv][Wv] float4 planes
     long pre_plane = 0;     // 16-byte elements per plane of `pre`
+    float *part = nullptr;  // scratch for the split-K tail (raw accumulators of K slices); null: never split
+    size_t part_bytes = 0;
 };
+// scratch that lets every layer split its partial round: 512 work items of 64 x 1024 accumulators
+static const size_t kSplitScratchBytes = (size_t)512 * 64 * 1024 * 4;
 int nd_launch_conv(const ConvDesc &d, hipStream_t stream);
 static inline int nd_launch_conv_f32(const ConvDesc &d, hipStream_t stream) { return nd_launch_conv(d, stream); }
 int nd_conv_variant_count();

@@ -83,6 +83,7 @@ Blob blob_layout() {
 enum UB { XIN, I1, CAT4, Q1, D1, CAT3, Q2, D2, CAT2, Q3, D3, CAT1, Q4, D4, X5, U1A, U1B, U2A, U2B, U3A, U3B, U4A, U4B, NUB };
 struct UPlan {
     QpBuf buf[NUB];
+    float *split;
     size_t bytes;
 };
 UPlan make_plan(int h, int w, int B, char *base) {
@@ -114,6 +115,8 @@ UPlan make_plan(int h, int w, int B, char *base) {
     add(U2A, 128, 2, 1); add(U2B, 128, 2, 0);
     add(U3A, 64, 1, 1); add(U3B, 64, 1, 0);
     add(U4A, 64, 0, 1); add(U4B, 64, 0, 0);
+    p.split = (float *)(base + off);
+    off += kSplitScratchBytes;
     p.bytes = off;
     return p;
 }
@@ -226,6 +229,8 @@ extern "C" int nd_unet_forward(int dtype, const void *packed, const float *x, fl
         d.out = pl.buf[st.dst];
         d.out_plane0 = st.dst_plane0;
         d.variant = -1;
+        d.part = pl.split;
+        d.part_bytes = kSplitScratchBytes;
         ND_TRY(nd_launch_conv_f32(d, s));
     }
     const float *fw = blob + bl.off[L.size() - 1];

@@ -209,6 +209,7 @@ extern "C" double nd_utnet_flops(int funit, int cs) {
 namespace {
 struct LayerPlan {
     QpBuf in, out;
+    float *split;
     size_t bytes;
 };
 LayerPlan layer_plan(int kind, int B, int cin, int cout, int h, int w, char *base, int dt = ND_F32) {
@@ -240,6 +241,9 @@ LayerPlan layer_plan(int kind, int B, int cin, int cout, int h, int w, char *bas
     p.out.pstride = (long)B * oh * ow;
     p.out.base = (float *)(base + off);
     off += ((size_t)p.out.planes * p.out.pstride + 64) * 16;
+    off = (off + 255) & ~(size_t)255;
+    p.split = (float *)(base + off);
+    off += kSplitScratchBytes;
     p.bytes = off;
     return p;
 }
@@ -276,6 +280,8 @@ extern "C" int nd_layer_forward(int kind, int act, float slope, int dtype, const
     d.out = pl.out;
     d.out_plane0 = 0;
     d.variant = variant;
+    d.part = pl.split;
+    d.part_bytes = kSplitScratchBytes;
     ND_TRY(nd_launch_conv(d, s));
     ND_TRY(nd_launch_qp_to_nchw(pl.out, 0, y, cout, s));
     return ND_OK;
@@ -363,6 +369,8 @@ extern "C" int nd_conv_bench(int kind, int dtype, int batch, int cin, int cout, 
     d.out = pl.out;
     d.out_plane0 = 0;
     d.variant = variant;
+    d.part = pl.split;
+    d.part_bytes = kSplitScratchBytes;
     ND_TRY(nd_launch_conv(d, s));  // warm-up (also validates the variant)
     hipEvent_t e0, e1;
     ND_HIP(hipEventCreate(&e0));

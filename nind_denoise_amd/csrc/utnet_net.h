@@ -114,6 +114,7 @@ enum Buf { X0, A1, CAT4, P1, A2, CAT3, P2, A3, CAT2, P3, A4, CAT1, P4, BT0, BT1,
 
 struct Plan {
     QpBuf buf[NBUF];
+    float *split;   // split-K scratch shared by every conv launch of the stream (kSplitScratchBytes)
     size_t bytes;
 };
 
@@ -169,6 +170,8 @@ Plan make_plan(int f, int ch_, int cw_, int cap, int nimg, char *base, int dt) {
     add(T3B, 2 * f, l2 + 4, 0);
     add(T4A, f, l1 + 2, 2);
     add(T4B, f, l1 + 4, 0);
+    p.split = (float *)(base + off);
+    off += kSplitScratchBytes;
     p.bytes = off;
     return p;
 }
@@ -221,6 +224,8 @@ int run_stack(int f, int act, int dt, const float *blob, const Plan &pl, hipStre
         d.out = pl.buf[st.dst];
         d.out_plane0 = st.dst_plane0_mul * f / cpp;
         d.variant = -1;
+        d.part = pl.split;
+        d.part_bytes = kSplitScratchBytes;
         ND_TRY(nd_launch_conv(d, s));
     }
     if (ev) ND_HIP(hipEventRecord(ev[si], s));

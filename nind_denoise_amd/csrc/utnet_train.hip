@@ -589,6 +589,8 @@ extern "C" int nd_utnet_train_step(int funit, const float *params, float *grads,
             d.out = t.g[st.src];
             d.out_plane0 = 0;
             d.variant = -1;
+            d.part = t.fwd.split;
+            d.part_bytes = kSplitScratchBytes;
             ND_TRY(nd_launch_conv(d, s));
         }
     }

@@ -29,6 +29,16 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture
+def whole_k(dev):
+    """Plumbing tests that compare two groupings of the same tiles bit for bit run with the split-K tail off: with it on, a
+    tile's fp32 sums may be re-associated depending on where the tile sits in its batch (see nd_conv_split_enable)."""
+    lib = _lib.load()
+    was = lib.nd_conv_split_enable(0)
+    yield
+    lib.nd_conv_split_enable(was)
+
+
 def assert_close(y, ref, what=""):
     y = y.detach().float().cpu()
     ref = ref.detach().float().cpu()
@@ -119,6 +129,51 @@ def test_layer_parity(dev, case):
     slope = 0.13
     y = layer_forward(dev, kind, x, w, b, act, slope)
     assert_close(y, ref_layer(kind, x, w, b, act, slope), str(case))
+
+
+SPLIT_CASES = [
+    # the deep, few-pixel layers of a training batch (UtNet(64), crop 136, 30 crops): fewer tiles than CUs -> K is split
+    ("conv3", 30, 512, 1024, 5, 5, "PReLU"),     # bottom.0: 9 valid pixels per image, tiles run across the whole batch
+    ("convT3", 30, 1024, 1024, 3, 3, "PReLU"),   # bottom.2
+    ("convT3", 6, 1024, 512, 10, 10, "PReLU"),   # tconvs1.0
+    ("conv3", 4, 256, 512, 12, 12, "ELU"),       # generic activation through the finish kernel
+    ("convT2s2", 8, 256, 128, 5, 5, "none"),     # pixel-shuffle store in the finish kernel
+    ("conv1", 3, 512, 64, 9, 9, "none"),
+    ("conv3", 70, 64, 64, 66, 66, "PReLU"),      # > 1 round of tiles: whole tiles first, only the tail round is split
+]
+
+
+@pytest.mark.parametrize("case", SPLIT_CASES, ids=lambda c: "-".join(str(v) for v in c))
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_layer_split_k(dev, case, dtype):
+    """Split-K tail (conv_f32.hip: plan_split / k_split_finish): same result as the unsplit launch up to fp32 re-association,
+    and both match torch."""
+    kind, B, cin, cout, H, W, act = case
+    k = {"conv3": 3, "convT3": 3, "convT2s2": 2, "conv1": 1}[kind]
+    x = rnd((B, cin, H, W), 1)
+    bound = 1.0 / np.sqrt(cin * k * k)
+    wshape = (cout, cin, k, k) if kind in ("conv3", "conv1") else (cin, cout, k, k)
+    w = rnd(wshape, 2, bound * 1.7)
+    b = rnd((cout,), 3, 0.2)
+    if dtype == "bf16":
+        x, w = x.to(torch.bfloat16).float(), w.to(torch.bfloat16).float()
+    lib = _lib.load()
+    y_on = layer_forward(dev, kind, x, w, b, act, 0.13, dtype=dtype)
+    was = lib.nd_conv_split_enable(0)
+    try:
+        y_off = layer_forward(dev, kind, x, w, b, act, 0.13, dtype=dtype)
+    finally:
+        lib.nd_conv_split_enable(was)
+    ref = ref_layer(kind, x, w, b, act, 0.13)
+    if dtype == "f32":
+        assert_close(y_on, ref, f"{case} split")
+        assert_close(y_off, ref, f"{case} unsplit")
+        assert (y_on - y_off).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    else:
+        # 16-bit storage of the result: one bf16 rounding of the same fp32 sums (up to their re-association)
+        tol = 2.0 ** -7 * max(1.0, ref.abs().max().item())
+        assert (y_on.cpu() - ref).abs().max().item() <= tol and (y_off.cpu() - ref).abs().max().item() <= tol
+        assert (y_on - y_off).abs().max().item() <= tol
 
 
 def test_layer_asymmetric_identity(dev):
@@ -279,10 +334,21 @@ def test_utnet_f64_cs264_golden(dev, golden_dir):
     net = net.eval().to(dev)
     x = torch.from_numpy(d["x"]).to(dev)
     err = assert_close(net(x), torch.from_numpy(d["y"]), "utnet f64 cs264")
-    # batch independence: the same tile inside a batch of 3 gives the same bits
+    # run-to-run determinism: the same batch gives the same bits.  Across batch compositions the split-K tail of a launch
+    # (nind_hip.h: nd_conv_split_enable) may re-associate a tile's fp32 sums, so that comparison carries a tolerance;
+    # with the split switched off a tile's bits do not depend on the batch around it
     xb = torch.cat([x, x.flip(3), x])
     yb = net(xb)
-    assert torch.equal(yb[0], yb[2]) and torch.equal(yb[0], net(x)[0])
+    assert torch.equal(yb, net(xb))
+    assert (yb[0] - net(x)[0]).abs().max().item() < 1e-5 and (yb[0] - yb[2]).abs().max().item() < 1e-5
+    lib = _lib.load()
+    was = lib.nd_conv_split_enable(0)
+    try:
+        yb = net(xb)
+        assert torch.equal(yb[0], yb[2]) and torch.equal(yb[0], net(x)[0])
+        assert_close(yb[:1], torch.from_numpy(d["y"]), "utnet f64 cs264, split-K off")
+    finally:
+        lib.nd_conv_split_enable(was)
     print(f"utnet f64 cs264 max abs err {err:.3e}")
 
 
@@ -310,7 +376,7 @@ def test_utnet_rejects_invalid_cs_and_cpu(dev):
         UtNet(funit=8)(torch.zeros(1, 3, 104, 104))
 
 
-def test_frame_end_to_end_vs_oracle(dev):
+def test_frame_end_to_end_vs_oracle(dev, whole_k):
     # crop -> UtNet -> stitch on a small frame: fused device loop vs the oracle loop, and fused == unfused bit for bit
     from nind_denoise_amd import pipeline
     from nind_denoise_amd.networks.UtNet import UtNet
@@ -336,6 +402,11 @@ def test_frame_end_to_end_vs_oracle(dev):
     # a different batch size only changes how tiles are grouped, never the result
     out3 = pipeline.denoise_frame(net, img, cs, ucs, ol, batch=3)
     assert torch.equal(out, out3)
+    # split-K tail on (the default): same frame up to fp32 re-association of a few tiles' sums
+    _lib.load().nd_conv_split_enable(1)
+    out4 = pipeline.denoise_frame(net, img, cs, ucs, ol, batch=5)
+    assert_close(out4, torch.from_numpy(ref), "frame e2e, split-K on")
+    assert (out4 - out).abs().max().item() < 1e-5
 
 
 def test_cli_end_to_end(dev, tmp_path):
@@ -502,7 +573,7 @@ def test_utnet_half_storage_vs_fp32_oracle(dev, golden_dir, dtype, min_psnr):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
-def test_frame_half_storage_fused_equals_unfused(dev, dtype):
+def test_frame_half_storage_fused_equals_unfused(dev, dtype, whole_k):
     from nind_denoise_amd import pipeline
     from nind_denoise_amd.networks.UtNet import UtNet
     net = UtNet(funit=16)
@@ -538,7 +609,7 @@ def test_frame_engine_streams_frames_in_order(dev):
         eng.submit(np.zeros((3, 10, 10), dtype=np.float32))
 
 
-def test_reference_style_main_loop_with_dataloader(dev):
+def test_reference_style_main_loop_with_dataloader(dev, whole_k):
     # the reference's own loop shape (denoise_image.py:232-267): DataLoader over OneImageDS, model(ybatch), crop by
     # usefuldim, make_seamless_edges, canvas += in tile order -- driven here with this package's drop-in classes only;
     # must give the same bits as the fused device loop (row a4 / a8 of SURVEY.md section 8)
