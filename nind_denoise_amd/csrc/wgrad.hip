@@ -126,19 +126,35 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradParams p) {
 }
 
 // dW[(m*N + n)*taps_total + tap0 + t] = sum_ks partial[ks][t][m][n]
-__global__ void k_wgrad_reduce(const float *__restrict__ partial, int ksplit, int taps, int Mp, int Np, int M, int N,
-                               int taps_total, int tap0, float *__restrict__ dw) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+// One workgroup per 64 consecutive (t, m, n) outputs; its four waves each add every fourth slice (in order), then the
+// four sums are added in wave order: a fixed summation tree, so the result is deterministic.
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ partial, int ksplit, int taps, int Mp, int Np,
+                                                      int M, int N, int taps_total, int tap0, float *__restrict__ dw) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long idx = (long)blockIdx.x * 64 + lane;
     const long total = (long)taps * M * N;
-    if (idx >= total) return;
-    const int n = (int)(idx % N);
-    const int m = (int)((idx / N) % M);
-    const int t = (int)(idx / ((long)N * M));
+    const bool ok = idx < total;
+    const long ic = ok ? idx : total - 1;
+    const int n = (int)(ic % N);
+    const int m = (int)((ic / N) % M);
+    const int t = (int)(ic / ((long)N * M));
     const long slice = (long)taps * Mp * Np;
     const float *src = partial + ((long)t * Mp + m) * Np + n;
-    float s = 0.f;
-    for (int k = 0; k < ksplit; ++k) s += src[k * slice];
-    dw[((long)m * N + n) * taps_total + tap0 + t] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = w;
+    for (; k + 12 < ksplit; k += 16) {
+        const float v0 = src[(long)k * slice], v1 = src[(long)(k + 4) * slice], v2 = src[(long)(k + 8) * slice],
+                    v3 = src[(long)(k + 12) * slice];
+        s0 += v0;
+        s1 += v1;
+        s2 += v2;
+        s3 += v3;
+    }
+    for (; k < ksplit; k += 4) s0 += src[(long)k * slice];
+    red[w][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (w == 0 && ok) dw[((long)m * N + n) * taps_total + tap0 + t] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 // dst (C planes on its own grid) = zeros, except  dst[c][img][y + oy][x + ox] = src[c][img][y*ss + sy][x*ss + sx]
@@ -172,7 +188,7 @@ size_t nd_wgrad_partial_floats(int taps, int M, int N, long K, int *ksplit_out, 
     const int Mp = (M + 63) / 64 * 64, Np = (N + 63) / 64 * 64;
     const long chunks = (K + PC - 1) / PC;
     const long tiles = (long)(Mp / 64) * (Np / 64);
-    long ksplit = (768 + tiles - 1) / tiles;            // ~3 workgroups per CU over the whole launch
+    long ksplit = 512 / tiles;                          // <= 2 whole rounds of one workgroup per CU (LDS: one fits)
     if (ksplit > chunks) ksplit = chunks;
     if (ksplit < 1) ksplit = 1;
     const long cps = (chunks + ksplit - 1) / ksplit;
@@ -225,7 +241,7 @@ int nd_launch_wgrad(const QpBuf &A, int a_plane0, int M, const QpBuf &Bq, int b_
     }
     ND_HIP(hipGetLastError());
     const long total = (long)taps * M * N;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, partial, ksplit, taps, p.Mp,
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, partial, ksplit, taps, p.Mp,
                        p.Np, M, N, taps_total, tap0, dw);
     ND_HIP(hipGetLastError());
     return ND_OK;
