@@ -13,10 +13,13 @@
 // MFMA: v_mfma_f32_32x32x2_f32 with M = A channels, N = B channels, K = pixels (2 per instruction: lanes 0-31 pixel
 // 2s, lanes 32-63 pixel 2s+1).  Operands are single floats per lane read with ds_read_b32 from the quad-planar LDS
 // images; the plane stride is padded by 16 B so the 32 channels of a half wave hit 32 different banks.
-// Workgroup: 4 waves (2 x 2), tile 64 (M) x 64 (N) x all taps (9 accumulator tiles of 32x32 per wave = 144 VGPRs),
-// one K slice; K chunks of 62 pixels so that the B image of one kernel row (62 + 2 pixels) is exactly one 64-lane
+// Workgroup: tile 64 (M) x 64 (N) x all taps, one K slice.  3x3: 12 waves = (2 x 2 quadrants) x 3 kernel rows, each wave
+// owning the three kx accumulator tiles of its row (three waves per SIMD cover each other's barrier / LDS bubbles);
+// 1 tap: 4 waves.  K chunks of 62 pixels so that the B image of one kernel row (62 + 2 pixels) is exactly one 64-lane
 // LDS-DMA piece per plane.  Partial sums go to [kslice][tap][m][n]; k_wgrad_reduce adds the slices in a fixed order
 // (deterministic) and writes the torch weight layout.
+#include <stdlib.h>
+
 #include "nd_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -40,7 +43,7 @@ __device__ __forceinline__ void glds16w(const void *g, void *l) {
 }
 
 template <int TAPS>
-__global__ __launch_bounds__(256) void k_wgrad(WgradParams p) {
+__global__ __launch_bounds__(TAPS == 9 ? 768 : 256) void k_wgrad(WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KY = TAPS == 9 ? 3 : 1;          // kernel rows: one B image each
     constexpr int PC = TAPS == 9 ? 62 : 64;        // pixels per chunk
@@ -48,10 +51,13 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradParams p) {
     constexpr int APL = 16, BPL = 16;              // planes of the 64-channel tiles
     constexpr int A_BYTES = APL * PLANE;
     constexpr int STAGE = A_BYTES + KY * BPL * PLANE;
+    constexpr int NW = 4 * KY;                     // waves: (2 x 2 quadrants) x kernel rows
+    constexpr int TPW = TAPS == 9 ? 3 : 1;         // accumulator tiles per wave: the kx taps of its kernel row
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = (wave >> 1) & 1, wn = wave & 1;
+    const int ky = wave >> 2;                      // kernel row of this wave (3x3 only)
     const int i = lane & 31, h = lane >> 5;
     const int mb = blockIdx.x / p.nblk, nb = blockIdx.x - mb * p.nblk;
     const int ks = blockIdx.y;
@@ -66,30 +72,30 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradParams p) {
     auto fill = [&](int c, int s) {
         char *sb = smem + s * STAGE;
         const long p0 = k_begin + (long)c * PC;
-        for (int q = wave; q < APL + KY * BPL; q += 4) {
+        for (int q = wave; q < APL + KY * BPL; q += NW) {
             if (q < APL) {
                 int pl = mb * 16 + q;
                 pl = pl < a_planes ? pl : a_planes - 1;
                 glds16w(p.A + (long)pl * p.a_plane + p0 + lane, sb + q * PLANE);
             } else {
-                const int r = q - APL, ky = r / BPL;
-                int pl = nb * 16 + (r - ky * BPL);
+                const int r = q - APL, kr = r / BPL;
+                int pl = nb * 16 + (r - kr * BPL);
                 pl = pl < b_planes ? pl : b_planes - 1;
-                glds16w(p.B + (long)pl * p.b_plane + p0 + (long)ky * p.Wb + lane, sb + A_BYTES + r * PLANE);
+                glds16w(p.B + (long)pl * p.b_plane + p0 + (long)kr * p.Wb + lane, sb + A_BYTES + r * PLANE);
             }
         }
     };
 
-    f32x16 acc[TAPS];
+    f32x16 acc[TPW];
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t)
+    for (int t = 0; t < TPW; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    // per-lane LDS byte offsets of "my" channel in the A and B images
+    // per-lane LDS byte offsets of "my" channel in the A image and in the B image of my kernel row
     const int am = wm * 32 + i, bn = wn * 32 + i;
     const int aoff = (am >> 2) * PLANE + (am & 3) * 4 + h * 16;
-    const int boff = A_BYTES + (bn >> 2) * PLANE + (bn & 3) * 4 + h * 16;
+    const int boff = A_BYTES + ky * BPL * PLANE + (bn >> 2) * PLANE + (bn & 3) * 4 + h * 16;
 
     if (nchunks > 0) fill(0, 0);
     for (int c = 0; c < nchunks; ++c) {
@@ -99,17 +105,22 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradParams p) {
         const char *sb = smem + (c & 1) * STAGE;
         const long left = k_end - (k_begin + (long)c * PC);
         const int npix = left < PC ? (int)left : PC;     // the last chunk of a slice may be short
-#pragma unroll 2
-        for (int s = 0; s < PC / 2; ++s) {
-            const int pix = 2 * s;
-            float a = *(const float *)(sb + aoff + pix * 16);
-            if (pix + h >= npix) a = 0.f;
+        // operands of step s+1 are read while the MFMAs of step s run (explicit double buffer: the LDS latency of a
+        // read-then-use schedule would leave the matrix pipe idle a quarter of the time)
+        float av[2], bv[2][TPW];
+        auto ld = [&](int buf, int s) {
+            av[buf] = *(const float *)(sb + aoff + 2 * s * 16);
 #pragma unroll
-            for (int t = 0; t < TAPS; ++t) {
-                const int ky = TAPS == 9 ? t / 3 : 0, kx = TAPS == 9 ? t % 3 : 0;
-                const float b = *(const float *)(sb + boff + ky * BPL * PLANE + (pix + kx) * 16);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
-            }
+            for (int tt = 0; tt < TPW; ++tt) bv[buf][tt] = *(const float *)(sb + boff + (2 * s + tt) * 16);
+        };
+        ld(0, 0);
+#pragma unroll
+        for (int s = 0; s < PC / 2; ++s) {
+            if (s + 1 < PC / 2) ld((s + 1) & 1, s + 1);
+            __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of this step's MFMAs (the scheduler sinks them otherwise)
+            const float a = 2 * s + h < npix ? av[s & 1] : 0.f;
+#pragma unroll
+            for (int tt = 0; tt < TPW; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[s & 1][tt], acc[tt], 0, 0, 0);
         }
     }
 
@@ -117,12 +128,14 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradParams p) {
     const int n = nb * 64 + wn * 32 + i;
     float *out = p.partial + (long)ks * TAPS * p.Mp * p.Np;
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t)
+    for (int tt = 0; tt < TPW; ++tt) {
+        const int t = ky * TPW + tt;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = mb * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            out[((long)t * p.Mp + m) * p.Np + n] = acc[t][r];
+            out[((long)t * p.Mp + m) * p.Np + n] = acc[tt][r];
         }
+    }
 }
 
 // dW[(m*N + n)*taps_total + tap0 + t] = sum_ks partial[ks][t][m][n]
@@ -230,7 +243,7 @@ int nd_launch_wgrad(const QpBuf &A, int a_plane0, int M, const QpBuf &Bq, int b_
             ND_HIP(hipFuncSetAttribute((const void *)k_wgrad<9>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             set9 = true;
         }
-        hipLaunchKernelGGL(k_wgrad<9>, grid, dim3(256), lds, s, p);
+        hipLaunchKernelGGL(k_wgrad<9>, grid, dim3(768), lds, s, p);
     } else {
         static bool set1 = false;
         if (!set1) {
