@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=160, help="tiles per launch of the conv stack")
+    ap.add_argument("--batch", type=int, default=256, help="tiles per launch of the conv stack")
     ap.add_argument("--width", type=int, default=6000)
     ap.add_argument("--height", type=int, default=4000)
     ap.add_argument("--cs", type=int, default=264)
