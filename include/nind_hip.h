@@ -182,6 +182,19 @@ int nd_utnet_train_step(int funit, const float *params, float *grads, void *blob
 int nd_adam_step(float *params, const float *grads, float *m, float *v, float *vmax, size_t n, float lr, float beta1,
                  float beta2, float eps, int step, int amsgrad, void *stream);
 
+/* ---- image-quality scores of the eval harness ------------------------------------------
+ * Replace pt_helpers.get_losses (common/libs/pt_helpers.py:40-48): F.mse_loss, piqa.SSIM and piqa.MS_SSIM with piqa's
+ * defaults, reduction=None (common/libs/pt_losses.py:6-18 subtracts them from 1; so do the Python classes here).
+ * x, y: float32 [n, c, h, w] in HBM, values in [0, 1].  out: float32 [n] in HBM (nd_mse: one float).
+ * nd_ssim needs h, w >= 11; nd_ms_ssim needs h, w >= 161 (five scales of an 11-tap window) -- ND_EINVAL otherwise, where
+ * piqa raises from the convolution.  The workspace of nd_ssim_workspace_bytes serves all three. */
+size_t nd_ssim_workspace_bytes(int n, int c, int h, int w);
+int nd_ssim(const float *x, const float *y, int n, int c, int h, int w, float *out, void *workspace, size_t workspace_bytes,
+            void *stream);
+int nd_ms_ssim(const float *x, const float *y, int n, int c, int h, int w, float *out, void *workspace,
+               size_t workspace_bytes, void *stream);
+int nd_mse(const float *x, const float *y, size_t count, float *out, void *workspace, size_t workspace_bytes, void *stream);
+
 /* Kernel micro-benchmark: `iters` launches of one conv layer (variant -1 = automatic choice) on pseudo-random
  * quad-planar data carved from `workspace` (nd_layer_workspace_bytes + nd_layer_packed_bytes + 256 B); mean launch
  * duration from HIP events on `stream`.  Synchronises the stream. */

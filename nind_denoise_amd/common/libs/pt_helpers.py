@@ -3,7 +3,7 @@ Interface of /root/reference/src/nind_denoise/common/libs/pt_helpers.py:13-56 (c
 import numpy as np
 import torch
 
-from . import imgcodec, np_imgops
+from . import imgcodec, np_imgops, pt_losses
 
 
 def fpath_to_tensor(img_fpath, device=torch.device(type='cpu'), batch=False):
@@ -35,6 +35,22 @@ def tensor_to_imgfile(tensor, path):
         Image.fromarray(tensor.permute(1, 2, 0).cpu().numpy()).save(path)
     else:
         raise NotImplementedError(tensor.dtype)
+
+
+def get_losses(img1_fpath, img2_fpath, device=None):
+    """{'mse', 'ssim', 'msssim'} of two image files (pt_helpers.py:40-48); 'ssim' / 'msssim' are 1 - score.
+    The reference scores on the CPU through piqa; here the images go to the GPU and the scores come from libnind_hip.so."""
+    device = get_device() if device is None else torch.device(device)
+    if device.type != 'cuda':
+        raise RuntimeError('get_losses needs a GPU (no CPU fallback)')
+    img1 = fpath_to_tensor(img1_fpath, device=device).unsqueeze(0)
+    img2 = fpath_to_tensor(img2_fpath, device=device).unsqueeze(0)
+    assert img1.shape == img2.shape, f'{img1.shape=}, {img2.shape=}'
+    res = dict()
+    res['mse'] = pt_losses.mse(img1, img2).item()
+    res['ssim'] = pt_losses.SSIM_loss()(img1, img2).item()
+    res['msssim'] = pt_losses.MS_SSIM_loss()(img1, img2).item()
+    return res
 
 
 def get_device(device_n=None):

@@ -166,6 +166,34 @@ def copy_exif(args):
     exiv_dst.writeMetadata()
 
 
+def denoise_file(model, inpath, outpath, cs, ucs, overlap, batch=32, whole_image=False, pad=None, max_subpixels=None,
+                 device=None, verbose=True):
+    '''One image file through the device-resident crop -> infer -> stitch loop (the body of the reference's __main__,
+    denoise_image.py:228-270); also what denoise_dir runs per image, in process, instead of spawning this script.'''
+    ds = OneImageDS(inpath, cs, ucs, overlap, whole_image=whole_image, pad=pad, device=device)
+    if whole_image:
+        ybatch, usefuldims, _ = ds[0]
+        ybatch = ybatch[None]
+        if max_subpixels is not None and math.prod(ybatch.shape) > max_subpixels:
+            sys.exit(f'denoise_image.py: {ybatch.shape=}, {math.prod(ybatch.shape)=} > {max_subpixels=} for {inpath=}; aborting')
+        ud = usefuldims.tolist()
+        newimg = model(ybatch)[0][:, ud[1]:ud[3], ud[0]:ud[2]]
+    else:
+        if max_subpixels is not None and batch * 3 * cs * cs > max_subpixels:
+            batch = max(1, max_subpixels // (3 * cs * cs))
+            if 3 * cs * cs > max_subpixels:
+                sys.exit(f'denoise_image.py: tile of {3 * cs * cs} sub-pixels > {max_subpixels=} for {inpath=}; aborting')
+        nbatches = int(math.ceil(len(ds) / batch))
+
+        def progress(n, t0, cnt):
+            if verbose:
+                print(str(n) + '/' + str(nbatches))
+        newimg = pipeline.denoise_frame(model, ds.inimg, cs, ucs, overlap, batch=batch, progress=progress)
+    torch.cuda.synchronize()
+    pt_helpers.tensor_to_imgfile(newimg.cpu(), outpath)
+    return newimg
+
+
 def main(argv=None):
     args = parse_args(argv)
     assert args.model_path is not None
@@ -187,30 +215,9 @@ def main(argv=None):
                                               device=device, models_dpath=args.models_dpath)
     model.eval()
     model = model.to(device)
-    ds = OneImageDS(args.input, args.cs, args.ucs, args.overlap, whole_image=args.whole_image, pad=args.pad, device=device)
-    fsheight, fswidth = ds.height, ds.width
-    batch = args.batch_size or 32
-
     start_time = time.time()
-    if args.whole_image:
-        ybatch, usefuldims, _ = ds[0]
-        ybatch = ybatch[None]
-        if args.max_subpixels is not None and math.prod(ybatch.shape) > args.max_subpixels:
-            sys.exit(f'denoise_image.py: {ybatch.shape=}, {math.prod(ybatch.shape)=} > {args.max_subpixels=} for {args.input=}; aborting')
-        ud = usefuldims.tolist()
-        newimg = model(ybatch)[0][:, ud[1]:ud[3], ud[0]:ud[2]]
-    else:
-        if args.max_subpixels is not None and batch * 3 * args.cs * args.cs > args.max_subpixels:
-            batch = max(1, args.max_subpixels // (3 * args.cs * args.cs))
-            if 3 * args.cs * args.cs > args.max_subpixels:
-                sys.exit(f'denoise_image.py: tile of {3 * args.cs * args.cs} sub-pixels > {args.max_subpixels=} for {args.input=}; aborting')
-        nbatches = int(math.ceil(len(ds) / batch))
-
-        def progress(n, t0, cnt):
-            print(str(n) + '/' + str(nbatches))
-        newimg = pipeline.denoise_frame(model, ds.inimg, args.cs, args.ucs, args.overlap, batch=batch, progress=progress)
-    torch.cuda.synchronize()
-    pt_helpers.tensor_to_imgfile(newimg.cpu(), args.output)
+    denoise_file(model, args.input, args.output, args.cs, args.ucs, args.overlap, batch=args.batch_size or 32,
+                 whole_image=args.whole_image, pad=args.pad, max_subpixels=args.max_subpixels, device=device)
     print(f'Denoised image written to {args.output}')
     copy_exif(args)
     print(f'Wrote denoised image to {args.output}')
