@@ -245,8 +245,9 @@ def main():
     if rank == 0:
         flop_frame = net.flops_per_tile(cs) * total
         out["end_to_end_tflops"] = round(flop_frame * args.steps / dt / 1e12, 3)
-        if not args.no_roofline and world == 1:
-            b = min(args.batch, total)
+        if not args.no_roofline:
+            # (N > 1: rank 0 profiles the conv stack at the size of its own tile shard; the other ranks wait at the end)
+            b = min(args.batch, hi - lo)
             steps = conv_stack_profile(net, cs, b, dev)
             log("conv stack profile done")
             conv_ms = sum(s["ms"] for s in steps if s["conv"])
@@ -286,6 +287,7 @@ def main():
             }
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
