@@ -300,6 +300,16 @@ def test_g24_frame_identity_full_size(dev):
     assert torch.equal(out, img)
 
 
+def test_g61_frame_identity_full_size(dev):
+    # BASELINE config 4 geometry at full size (9504x6336, cs=520 ucs=456 ol=64 -> 25x16 tiles): same property
+    from nind_denoise_amd import pipeline
+    assert pipeline.tile_count(9504, 6336, 520, 456, 64) == 400
+    g = torch.Generator(device=dev).manual_seed(61)
+    img = torch.rand((3, 6336, 9504), generator=g, device=dev)
+    out = pipeline.denoise_frame(lambda x: x, img, 520, 456, 64, batch=50)
+    assert torch.equal(out, img)
+
+
 # ---------------------------------------------------------------------------- networks
 
 def test_utnet_f8_golden(dev, golden_dir):
@@ -457,6 +467,13 @@ def test_utnet_f64_wide_tiles_vs_oracle(dev, cs):
     with torch.no_grad():
         ref = onet.utnet_forward(sd, x)
     assert_close(net(x.to(dev)), ref, f"f64 cs{cs}")
+    # BASELINE configs 3 / 4 at these tile sizes: 16-bit storage, fp32 accumulate (1e-3 applies to fp32 only -> PSNR bars)
+    for dtype, min_psnr in (("f16", 55.0), ("bf16", 38.0)):
+        y = net.set_compute_dtype(dtype)(x.to(dev)).float().cpu()
+        mse = ((y - ref) ** 2).mean().item()
+        psnr = 10 * np.log10(max(ref.abs().max().item(), 1e-12) ** 2 / max(mse, 1e-30))
+        assert torch.isfinite(y).all() and psnr >= min_psnr, (dtype, cs, psnr)
+    net.set_compute_dtype("f32")
 
 
 def test_utnet_non_square_and_whole_image(dev):
@@ -756,9 +773,10 @@ def test_weight_gradient_vs_autograd(dev, case):
         assert err <= 2e-5 * max(ref.abs().max().item(), 1.0) + 1e-5, (case, what, err, ref.abs().max().item())
 
 
-def _autograd_reference(sd, x, t, w_l1, w_mse):
+def _autograd_reference(sd, x, t, w_l1, w_mse, dtype=torch.float32):
     from oracle import networks as onet
-    params = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    params = {k: v.clone().to(dtype).requires_grad_() for k, v in sd.items()}
+    x, t = x.to(dtype), t.to(dtype)
     y = onet.utnet_forward(params, x)
     g = y.clip(0, 1)
     loss = w_l1 * F.l1_loss(g, t) + w_mse * F.mse_loss(g, t)
@@ -766,7 +784,7 @@ def _autograd_reference(sd, x, t, w_l1, w_mse):
     return y.detach(), loss.detach(), params
 
 
-@pytest.mark.parametrize("funit,cs,B,w_l1,w_mse", [(8, 104, 2, 0.0, 1.0), (16, 120, 3, 0.3, 0.7)])
+@pytest.mark.parametrize("funit,cs,B,w_l1,w_mse", [(8, 104, 2, 0.0, 1.0), (16, 120, 3, 0.3, 0.7), (64, 136, 2, 0.5, 0.5)])
 def test_training_step_gradients_vs_autograd(dev, funit, cs, B, w_l1, w_mse):
     # BASELINE config 5 building block: forward + loss + backward against torch autograd on the oracle (CPU)
     from nind_denoise_amd.networks.UtNet import UtNet
@@ -780,17 +798,25 @@ def test_training_step_gradients_vs_autograd(dev, funit, cs, B, w_l1, w_mse):
     t = (x * 0.9 + 0.05 * torch.rand(B, 3, cs, cs, generator=g)).clip(0, 1)
     y, loss = tr.forward_backward(x, t)
     torch.cuda.synchronize()
-    y_ref, loss_ref, params = _autograd_reference(sd, x, t, w_l1, w_mse)
+    # the production width: 23 layers of up to 9216-term fp32 sums and gradients spanning 1e-1 .. 1e-7 (these synthetic
+    # weights make them vanish towards the bottom).  There fp32 autograd itself is 3e-4 .. 5e-4 off float64 autograd on the
+    # smallest tensors, and the MFMA's sequential fmaf chains ~3-10x that; so that case is checked against float64 with a bar
+    # tied to torch's own fp32 error
+    wide = funit == 64
+    y_ref, loss_ref, params = _autograd_reference(sd, x, t, w_l1, w_mse, torch.float64 if wide else torch.float32)
+    params32 = _autograd_reference(sd, x, t, w_l1, w_mse)[2] if wide else None
+    y_ref, loss_ref = y_ref.float(), loss_ref.float()
     assert_close(y, y_ref, "training forward")
     assert abs(loss.item() - loss_ref.item()) <= 1e-5 * max(1.0, abs(loss_ref.item()))
     worst = 0.0
     for name, p in params.items():
         got = tr.grad_of(name).cpu()
-        ref = p.grad
+        ref = p.grad.float()
         scale = max(ref.abs().max().item(), 1e-8)
         err = (got - ref).abs().max().item() / scale
         worst = max(worst, err)
-        assert torch.isfinite(got).all() and err <= 2e-3, (name, err, scale)
+        bar = 2e-3 + (10 * (params32[name].grad - ref).abs().max().item() / scale if wide else 0.0)
+        assert torch.isfinite(got).all() and err <= bar, (name, err, bar, scale)
     print(f"training step f{funit} cs{cs}: worst relative gradient error {worst:.2e}")
 
 
