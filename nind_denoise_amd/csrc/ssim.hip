@@ -223,15 +223,12 @@ int upload_window() {
     static bool done = false;
     if (done) return ND_OK;
     float g[kWin];
-    double sum = 0;
+    float s = 0.f;   // fp32 throughout, like torch's kernel / kernel.sum()
     for (int k = 0; k < kWin; ++k) {
         const float d = (float)k - (kWin - 1) / 2.f;
         g[k] = expf(-(d * d) / (2.f * 1.5f * 1.5f));
-        sum += g[k];
+        s += g[k];
     }
-    float s = 0.f;
-    for (int k = 0; k < kWin; ++k) s += g[k];   // fp32 sum like torch's kernel / kernel.sum()
-    (void)sum;
     for (int k = 0; k < kWin; ++k) g[k] /= s;
     ND_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_gauss), g, sizeof(g)));
     done = true;
