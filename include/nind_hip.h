@@ -168,7 +168,9 @@ int nd_layer_wgrad(int kind, const float *x_nchw, const float *dy_nchw, int batc
  * Parameters and gradients are flat float buffers in state-dict order (nd_utnet_tensor_name / nd_utnet_param_range):
  * one buffer for the data-parallel all-reduce and for the optimizer.  nd_utnet_train_step = device-side weight
  * packing + forward + loss + backward:
- *     loss = w_l1 * mean|clip(y,0,1) - target| + w_mse * mean (clip(y,0,1) - target)^2        (y = net(x))
+ *     loss = w_l1 * mean|g - t| + w_mse * mean (g - t)^2 + w_ssim * mean_n(1 - SSIM_n(g, t))
+ *            + w_msssim * mean_n(1 - MS-SSIM_n(g, t)),        g = clip(net(x), 0, 1), t = target   (nn_common.py:198-241;
+ *     the SSIM terms as in nd_ssim_loss_grad; MS-SSIM needs cs >= 161, so it cannot be used on 136-pixel crops)
  * x, target, y_out: [batch,3,cs,cs] NCHW fp32 in HBM (cs = 16k+56, e.g. 136 / 184); loss_out: one float in HBM.
  * nd_adam_step = torch.optim.Adam(lr, betas, eps, amsgrad) on the flat buffers (nn_common.py:185). */
 size_t nd_utnet_param_count(int funit);
@@ -177,8 +179,8 @@ size_t nd_utnet_train_blob_bytes(int funit);
 size_t nd_utnet_train_workspace_bytes(int funit, int cs, int batch);
 int nd_utnet_train_workspace_init(void *workspace, size_t workspace_bytes, int funit, int cs, int batch, void *stream);
 int nd_utnet_train_step(int funit, const float *params, float *grads, void *blobs, const float *x_nchw,
-                        const float *target_nchw, float *y_out_nchw, float w_l1, float w_mse, float *loss_out,
-                        int batch, int cs, void *workspace, size_t workspace_bytes, void *stream);
+                        const float *target_nchw, float *y_out_nchw, float w_l1, float w_mse, float w_ssim, float w_msssim,
+                        float *loss_out, int batch, int cs, void *workspace, size_t workspace_bytes, void *stream);
 int nd_adam_step(float *params, const float *grads, float *m, float *v, float *vmax, size_t n, float lr, float beta1,
                  float beta2, float eps, int step, int amsgrad, void *stream);
 
@@ -194,6 +196,13 @@ int nd_ssim(const float *x, const float *y, int n, int c, int h, int w, float *o
 int nd_ms_ssim(const float *x, const float *y, int n, int c, int h, int w, float *out, void *workspace,
                size_t workspace_bytes, void *stream);
 int nd_mse(const float *x, const float *y, size_t count, float *out, void *workspace, size_t workspace_bytes, void *stream);
+
+/* The same two scores as differentiable training losses (nn_common.py:170-177, 226-241: criterions['SSIM'|'MSSSIM'], weighted
+ * sum, loss.backward()):   loss_acc[0] += weight * mean_n (1 - score_n(x, y));   gx = (accumulate ? gx : 0) + d(that)/dx.
+ * x = generated batch, y = target, gx: float32 [n, c, h, w]; multiscale 0 = SSIM, 1 = MS-SSIM (h, w >= 161). */
+size_t nd_ssim_loss_workspace_bytes(int n, int c, int h, int w);
+int nd_ssim_loss_grad(const float *x, const float *y, int n, int c, int h, int w, int multiscale, float weight,
+                      float *loss_acc, float *gx, int accumulate, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Kernel micro-benchmark: `iters` launches of one conv layer (variant -1 = automatic choice) on pseudo-random
  * quad-planar data carved from `workspace` (nd_layer_workspace_bytes + nd_layer_packed_bytes + 256 B); mean launch

@@ -68,11 +68,14 @@ _SIGNATURES = {
     "nd_utnet_train_workspace_bytes": (c_size_t, [c_int] * 3),
     "nd_utnet_train_workspace_init": (c_int, [c_void_p, c_size_t, c_int, c_int, c_int, c_void_p]),
     "nd_utnet_train_step": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
-                                    c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+                                    c_float, c_float, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "nd_adam_step": (c_int, [c_void_p] * 5 + [c_size_t, c_float, c_float, c_float, c_float, c_int, c_int, c_void_p]),
     "nd_ssim_workspace_bytes": (c_size_t, [c_int] * 4),
     "nd_ssim": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_void_p, c_size_t, c_void_p]),
     "nd_ms_ssim": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "nd_ssim_loss_workspace_bytes": (c_size_t, [c_int] * 4),
+    "nd_ssim_loss_grad": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_float, c_void_p, c_void_p, c_int, c_void_p, c_size_t,
+                                  c_void_p]),
     "nd_mse": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t, c_void_p]),
     "nd_conv_bench": (c_int, [c_int] * 9 + [c_void_p, c_size_t, c_void_p, POINTER(c_float)]),
     "nd_num_conv_variants": (c_int, []),

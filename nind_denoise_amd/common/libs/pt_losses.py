@@ -2,8 +2,9 @@
 Interface of /root/reference/src/nind_denoise/common/libs/pt_losses.py:6-18: ``SSIM_loss()(input, target)`` and
 ``MS_SSIM_loss()(input, target)`` return ``1 - piqa.SSIM / piqa.MS_SSIM`` per sample (``reduction=None``: shape [N]).
 The arithmetic is piqa's published algorithm with piqa's defaults (piqa itself is not installed: parity unpinned, see
-oracle/losses.py); it runs in ``libnind_hip.so`` (csrc/ssim.hip).  Forward only: these classes score images
-(``pt_helpers.get_losses``, ``denoise_dir``); they are not differentiable training losses."""
+oracle/losses.py); it runs in ``libnind_hip.so`` (csrc/ssim.hip).  Differentiable with respect to ``input`` (the generated
+batch), like the reference's classes when they are used as training criterions (nn_common.py:170-177): the backward pass is
+``nd_ssim_loss_grad``.  ``target`` is treated as a constant."""
 import torch
 
 from ... import _lib
@@ -45,11 +46,40 @@ def mse(input, target):
     return out[0]
 
 
+class _LossFn(torch.autograd.Function):
+    """1 - score per sample; backward through nd_ssim_loss_grad (one call per sample weight vector)."""
+
+    @staticmethod
+    def forward(ctx, input, target, multiscale):
+        ctx.multiscale = multiscale
+        ctx.save_for_backward(input, target)
+        return 1 - _score("nd_ms_ssim" if multiscale else "nd_ssim", input, target)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        input, target = ctx.saved_tensors
+        x, y = _prep(input, target)
+        n, c, h, w = x.shape
+        lib = _lib.load()
+        wsb = lib.nd_ssim_loss_workspace_bytes(1, c, h, w)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+        gx = torch.empty_like(x)
+        scratch = torch.zeros(1, dtype=torch.float32, device=x.device)
+        go = grad_out.detach().to(torch.float32).cpu()
+        with torch.cuda.device(x.device):
+            for i in range(n):      # d(1 - score_i)/dx_i scaled by the incoming gradient of sample i
+                _lib.check(lib.nd_ssim_loss_grad(x[i:i + 1].data_ptr(), y[i:i + 1].data_ptr(), 1, c, h, w,
+                                                 1 if ctx.multiscale else 0, float(go[i]), scratch.data_ptr(),
+                                                 gx[i:i + 1].data_ptr(), 0, ws.data_ptr(), wsb, _lib.stream_ptr(x.device)),
+                           "nd_ssim_loss_grad")
+        return gx.to(input.dtype), None, None
+
+
 class SSIM_loss(torch.nn.Module):
     def forward(self, input, target):
-        return 1 - _score("nd_ssim", input, target)
+        return _LossFn.apply(input, target, False)
 
 
 class MS_SSIM_loss(torch.nn.Module):
     def forward(self, input, target):
-        return 1 - _score("nd_ms_ssim", input, target)
+        return _LossFn.apply(input, target, True)

@@ -206,7 +206,7 @@ static int pick_variant(const ConvDesc &d, int M) {
     return g0 + 4;
 }
 
-static int g_lds_set[64] = {0};
+static int g_lds_set[16][64] = {{0}};   // per device: function attributes belong to the device's copy of the code object
 
 int nd_launch_conv(const ConvDesc &d, hipStream_t stream) {
     const int taps = nd_taps(d.kind);
@@ -274,9 +274,12 @@ int nd_launch_conv(const ConvDesc &d, hipStream_t stream) {
     bool cross = true;
     const size_t lds = variant_lds(V, d.in, &cross, &p.G);
     if (lds > kMaxLds) ND_FAIL(ND_EINVAL, "conv: %zu B of LDS needed (row width %d too large for variant %s)", lds, p.Wb, V.name);
-    if ((int)lds > g_lds_set[v]) {
+    int dev = 0;
+    ND_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) ND_FAIL(ND_EINVAL, "conv: device index %d", dev);
+    if ((int)lds > g_lds_set[dev][v]) {
         ND_HIP(hipFuncSetAttribute((const void *)V.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        g_lds_set[v] = (int)lds;
+        g_lds_set[dev][v] = (int)lds;
     }
     if (!g_num_cus) {
         int dev = 0;

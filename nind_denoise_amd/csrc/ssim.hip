@@ -188,13 +188,174 @@ __global__ __launch_bounds__(256) void k_sum_scale(const float *__restrict__ par
     if (threadIdx.x == 0) out[0] = red[0] * scale;
 }
 
+// ------------------------------------------------------------------ backward (SSIM / MS-SSIM as training losses)
+// F = mean_q phi(q) per plane, phi = ss (SSIM; last MS-SSIM scale) or cs (other MS-SSIM scales):
+//   dF/dx(u) = 1/Nq * [ (G^T A)(u) + 2 x(u) (G^T B)(u) + y(u) (G^T C)(u) ],   A = dphi/dmu_x, B = dphi/dE[xx], C = dphi/dE[xy]
+// (G^T = the same separable window applied as a FULL correlation over the valid score positions q).
+// One workgroup: 16 x 16 gradient pixels <- derivative maps at 26 x 26 score positions <- a 36 x 36 patch of x and y.
+// gx(u) (+)= coef[plane] * dF/dx(u) + gcoarse(u/2) / (pixels of that pooling window)      [avg_pool2d(2, ceil) backward]
+constexpr int kBT = 16;
+constexpr int kBQ = kBT + kWin - 1;    // 26 score positions per side
+constexpr int kBI = kBQ + kWin - 1;    // 36 input pixels per side
+__global__ __launch_bounds__(256) void k_ssim_bwd_tile(const float *__restrict__ x, const float *__restrict__ y, int H, int W,
+                                                       const float *__restrict__ coef, int use_ss,
+                                                       const float *__restrict__ gcoarse, int H2, int W2,
+                                                       float *__restrict__ gx, int accumulate) {
+    __shared__ float sx[kBI][kBI + 1], sy[kBI][kBI + 1];
+    __shared__ float hm[5][kBI][kBQ + 1];
+    __shared__ float dm[3][kBQ][kBQ + 1];
+    __shared__ float rm[3][kBQ][kBT + 1];
+    const int plane = blockIdx.z;
+    const int ux0 = blockIdx.x * kBT, uy0 = blockIdx.y * kBT;   // first gradient pixel of the tile
+    const int qx0 = ux0 - (kWin - 1), qy0 = uy0 - (kWin - 1);   // first score position it depends on
+    const float *xp = x + (size_t)plane * H * W, *yp = y + (size_t)plane * H * W;
+    for (int i = threadIdx.x; i < kBI * kBI; i += 256) {
+        const int r = i / kBI, c = i - r * kBI;
+        const int gy_ = qy0 + r, gx_ = qx0 + c;
+        const bool in = gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W;
+        sx[r][c] = in ? xp[(size_t)gy_ * W + gx_] : 0.f;
+        sy[r][c] = in ? yp[(size_t)gy_ * W + gx_] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kBI * kBQ; i += 256) {
+        const int r = i / kBQ, c = i - r * kBQ;
+        float a = 0.f, b = 0.f, aa = 0.f, bb = 0.f, ab = 0.f;
+#pragma unroll
+        for (int k = 0; k < kWin; ++k) {
+            const float g = c_gauss[k], u = sx[r][c + k], v = sy[r][c + k];
+            a += g * u;
+            b += g * v;
+            aa += g * (u * u);
+            bb += g * (v * v);
+            ab += g * (u * v);
+        }
+        hm[0][r][c] = a;
+        hm[1][r][c] = b;
+        hm[2][r][c] = aa;
+        hm[3][r][c] = bb;
+        hm[4][r][c] = ab;
+    }
+    __syncthreads();
+    const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;
+    const int Hv = H - kWin + 1, Wv = W - kWin + 1;
+    for (int i = threadIdx.x; i < kBQ * kBQ; i += 256) {
+        const int r = i / kBQ, c = i - r * kBQ;
+        const int qy = qy0 + r, qx = qx0 + c;
+        float A = 0.f, B = 0.f, C = 0.f;
+        if (qy >= 0 && qy < Hv && qx >= 0 && qx < Wv) {
+            float m[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < kWin; ++k) {
+                const float g = c_gauss[k];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) m[q] += g * hm[q][r + k][c];
+            }
+            const float mx = m[0], my = m[1];
+            const float a2 = 2.f * (m[4] - mx * my) + c2, b2 = (m[2] - mx * mx) + (m[3] - my * my) + c2;
+            const float cs = a2 / b2;
+            const float dcs_mx = 2.f / b2 * (mx * cs - my), dcs_xx = -cs / b2, dcs_xy = 2.f / b2;
+            if (use_ss) {
+                const float b1 = mx * mx + my * my + c1, l = (2.f * mx * my + c1) / b1;
+                A = 2.f / b1 * (my - mx * l) * cs + l * dcs_mx;
+                B = l * dcs_xx;
+                C = l * dcs_xy;
+            } else {
+                A = dcs_mx;
+                B = dcs_xx;
+                C = dcs_xy;
+            }
+        }
+        dm[0][r][c] = A;
+        dm[1][r][c] = B;
+        dm[2][r][c] = C;
+    }
+    __syncthreads();
+    // full correlation: out(u) = sum_{k} g[k] * d(u - k) ; local index of q = u - k is (u_local + 10 - k)
+    for (int i = threadIdx.x; i < kBQ * kBT; i += 256) {
+        const int r = i / kBT, c = i - r * kBT;
+        float a = 0.f, b = 0.f, d = 0.f;
+#pragma unroll
+        for (int k = 0; k < kWin; ++k) {
+            const float g = c_gauss[k];
+            a += g * dm[0][r][c + kWin - 1 - k];
+            b += g * dm[1][r][c + kWin - 1 - k];
+            d += g * dm[2][r][c + kWin - 1 - k];
+        }
+        rm[0][r][c] = a;
+        rm[1][r][c] = b;
+        rm[2][r][c] = d;
+    }
+    __syncthreads();
+    const float cf = coef[plane];
+    {
+        const int r = threadIdx.x / kBT, c = threadIdx.x - r * kBT;
+        const int uy = uy0 + r, ux = ux0 + c;
+        if (uy < H && ux < W) {
+            float a = 0.f, b = 0.f, d = 0.f;
+#pragma unroll
+            for (int k = 0; k < kWin; ++k) {
+                const float g = c_gauss[k];
+                a += g * rm[0][r + kWin - 1 - k][c];
+                b += g * rm[1][r + kWin - 1 - k][c];
+                d += g * rm[2][r + kWin - 1 - k][c];
+            }
+            const float xv = sx[r + kWin - 1][c + kWin - 1], yv = sy[r + kWin - 1][c + kWin - 1];
+            float g = cf * (a + 2.f * xv * b + yv * d);
+            if (gcoarse) {
+                const int oy = uy >> 1, ox = ux >> 1;
+                const int ny = 2 * oy + 1 < H ? 2 : 1, nx = 2 * ox + 1 < W ? 2 : 1;
+                g += gcoarse[((size_t)plane * H2 + oy) * W2 + ox] / (float)(ny * nx);
+            }
+            float *dst = gx + ((size_t)plane * H + uy) * W + ux;
+            *dst = accumulate ? *dst + g : g;
+        }
+    }
+}
+
+// per-plane coefficients d loss / d F_scale (including 1/Nq) and the loss value.
+//   SSIM  (scales = 1): loss = weight * mean_n (1 - mean_c ss)
+//   MS-SSIM           : loss = weight * mean_n (1 - mean_c prod_s relu(v_s)^w_s)
+// one thread per sample; loss_acc[0] += sum (single thread, fixed order)
+struct Five { float v[kScales]; };
+__global__ void k_ssim_loss_coef(const float2 *__restrict__ stats, int n, int c, int scales, Five wts, float weight, Five inv_nq_,
+                                 float *__restrict__ coef, float *__restrict__ loss_acc) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const float *w = wts.v, *inv_nq = inv_nq_.v;
+    const int planes = n * c;
+    float total = 0.f;
+    for (int i = 0; i < n; ++i) {
+        float score = 0.f;
+        for (int ch = 0; ch < c; ++ch) {
+            const int p = i * c + ch;
+            if (scales == 1) {
+                score += stats[p].x;
+                coef[p] = -weight / (float)(n * c) * inv_nq[0];
+            } else {
+                float v[kScales], prod = 1.f;
+                for (int k = 0; k < kScales; ++k) {
+                    const float2 st = stats[(size_t)k * planes + p];
+                    v[k] = fmaxf(k + 1 < kScales ? st.y : st.x, 0.f);
+                    prod *= powf(v[k], w[k]);
+                }
+                score += prod;
+                for (int k = 0; k < kScales; ++k)
+                    coef[(size_t)k * planes + p] = v[k] > 0.f ? -weight / (float)(n * c) * w[k] * prod / v[k] * inv_nq[k] : 0.f;
+            }
+        }
+        total += 1.f - score / (float)c;
+    }
+    loss_acc[0] += weight * total / (float)n;
+}
+
 struct SsimPlan {
     int h[kScales], w[kScales];
     float *px[kScales], *py[kScales];   // pyramid levels 1.. (level 0 = the caller's tensors)
     float2 *partial, *stats;
+    float *pg[kScales];                 // training: gradient wrt pyramid levels 1..
+    float *coef;
     size_t bytes;
 };
-SsimPlan ssim_plan(int n, int c, int h, int w, char *base) {
+SsimPlan ssim_plan(int n, int c, int h, int w, char *base, bool with_grad = false) {
     SsimPlan p;
     size_t off = 0;
     const size_t planes = (size_t)n * c;
@@ -215,13 +376,25 @@ SsimPlan ssim_plan(int n, int c, int h, int w, char *base) {
     off += (planes * nblk * 8 + 255) & ~(size_t)255;
     p.stats = (float2 *)(base + off);
     off += (kScales * planes * 8 + 255) & ~(size_t)255;
+    p.pg[0] = nullptr;
+    if (with_grad) {
+        for (int i = 1; i < kScales; ++i) {
+            p.pg[i] = (float *)(base + off);
+            off += (planes * p.h[i] * p.w[i] * 4 + 255) & ~(size_t)255;
+        }
+        p.coef = (float *)(base + off);
+        off += (kScales * planes * 4 + 255) & ~(size_t)255;
+    }
     p.bytes = off;
     return p;
 }
 
 int upload_window() {
-    static bool done = false;
-    if (done) return ND_OK;
+    static bool done[64] = {false};   // __constant__ memory is per device
+    int dev = 0;
+    ND_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) ND_FAIL(ND_EINVAL, "ssim: device index %d", dev);
+    if (done[dev]) return ND_OK;
     float g[kWin];
     float s = 0.f;   // fp32 throughout, like torch's kernel / kernel.sum()
     for (int k = 0; k < kWin; ++k) {
@@ -231,7 +404,7 @@ int upload_window() {
     }
     for (int k = 0; k < kWin; ++k) g[k] /= s;
     ND_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_gauss), g, sizeof(g)));
-    done = true;
+    done[dev] = true;
     return ND_OK;
 }
 
@@ -304,6 +477,44 @@ extern "C" int nd_mse(const float *x, const float *y, size_t count, float *out, 
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_sqdiff_partial, dim3(1024), dim3(256), 0, s, x, y, count, (float *)ws);
     hipLaunchKernelGGL(k_sum_scale, dim3(1), dim3(256), 0, s, (const float *)ws, 1024, 1.f / (float)count, out);
+    ND_HIP(hipGetLastError());
+    return ND_OK;
+}
+
+// ------------------------------------------------------------------ SSIM / MS-SSIM as differentiable losses
+// loss_acc[0] += weight * mean_n (1 - score_n);   gx (+)= d(that) / dx      (x = generated batch, y = target; both [n,c,h,w])
+// Reference: nn_common.py:170-177, 226-241 (criterions['SSIM' | 'MSSSIM'] = pt_losses.*_loss, weighted sum, .backward()).
+extern "C" size_t nd_ssim_loss_workspace_bytes(int n, int c, int h, int w) {
+    if (n <= 0 || c <= 0 || h <= 0 || w <= 0) return 0;
+    return ssim_plan(n, c, h, w, nullptr, true).bytes;
+}
+
+extern "C" int nd_ssim_loss_grad(const float *x, const float *y, int n, int c, int h, int w, int multiscale, float weight,
+                                 float *loss_acc, float *gx, int accumulate, void *ws, size_t ws_bytes, void *stream) {
+    ND_TRY(check_shape(multiscale ? "nd_ssim_loss_grad (MS-SSIM)" : "nd_ssim_loss_grad", n, c, h, w,
+                       multiscale ? (kWin - 1) * 16 + 1 : kWin));
+    const SsimPlan p = ssim_plan(n, c, h, w, (char *)ws, true);
+    if (!ws || ws_bytes < p.bytes) ND_FAIL(ND_ENOMEM, "nd_ssim_loss_grad: workspace %zu B given, %zu B needed", ws_bytes, p.bytes);
+    hipStream_t s = (hipStream_t)stream;
+    const int scales = multiscale ? kScales : 1, planes = n * c;
+    ND_TRY(run_scales(x, y, n, c, p, scales, s));
+    Five wts, inv;
+    for (int i = 0; i < kScales; ++i) {
+        wts.v[i] = kMsWeights[i];
+        inv.v[i] = 1.f / ((float)(p.h[i] - kWin + 1) * (float)(p.w[i] - kWin + 1));
+    }
+    hipLaunchKernelGGL(k_ssim_loss_coef, dim3(1), dim3(64), 0, s, (const float2 *)p.stats, n, c, scales, wts, weight, inv, p.coef,
+                       loss_acc);
+    // coarsest scale first; every finer level adds the pooled-back gradient of the level below it
+    for (int i = scales - 1; i >= 0; --i) {
+        const float *cx = i ? p.px[i] : x, *cy = i ? p.py[i] : y;
+        float *dst = i ? p.pg[i] : gx;
+        const float *coarse = i + 1 < scales ? p.pg[i + 1] : nullptr;
+        dim3 g((p.w[i] + kBT - 1) / kBT, (p.h[i] + kBT - 1) / kBT, planes);
+        hipLaunchKernelGGL(k_ssim_bwd_tile, g, dim3(256), 0, s, cx, cy, p.h[i], p.w[i], p.coef + (size_t)i * planes,
+                           (multiscale && i + 1 < scales) ? 0 : 1, coarse, coarse ? p.h[i + 1] : 0, coarse ? p.w[i + 1] : 0, dst,
+                           i == 0 ? accumulate : 0);
+    }
     ND_HIP(hipGetLastError());
     return ND_OK;
 }

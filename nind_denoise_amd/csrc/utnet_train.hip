@@ -127,6 +127,18 @@ __global__ __launch_bounds__(256) void k_loss_grad(const float *__restrict__ y, 
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
+// SSIM / MS-SSIM act on clip(y, 0, 1) (nn_common.py:198-199): yc = clip(y);  later gy += [0 <= y <= 1] * g(yc)
+__global__ void k_clip01(const float *__restrict__ y, long n, float *__restrict__ yc) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        yc[i] = fminf(fmaxf(y[i], 0.f), 1.f);
+}
+__global__ void k_add_clip_grad(const float *__restrict__ y, const float *__restrict__ gc, long n, float *__restrict__ gy) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = y[i];
+        if (v >= 0.f && v <= 1.f) gy[i] += gc[i];
+    }
+}
+
 // data gradient of the final Conv2d(f,3,1) + crop: g[c][b][Y][X] = sum_co gy[co][b][Y-crop][X-crop] * w[co][c] (0 outside)
 __global__ void k_final_bwd_data(const float *__restrict__ gy, int S, const float *__restrict__ w, int cin, int crop,
                                  f32x4 *__restrict__ g, long gnp, int Hb, int Wb, int B) {
@@ -308,6 +320,9 @@ struct TrainPlan {
     size_t partial_floats;
     float *red;             // reduction scratch
     float *gy;              // d loss / d output  [B,3,S,S]
+    float *yclip, *gssim;   // SSIM / MS-SSIM terms: clip(y, 0, 1) and the gradient with respect to it  [B,3,S,S]
+    char *ssim_ws;          // nd_ssim_loss_workspace_bytes(B, 3, S, S)
+    size_t ssim_ws_bytes;
     size_t bytes;
 };
 constexpr int kRedFloats = 1 << 19;   // reduction scratch: >= 4 floats x planes x batch
@@ -392,6 +407,13 @@ TrainPlan make_train_plan(int f, int cs, int B, char *base) {
     t.gy = (float *)(base ? base + off : nullptr);
     off += (size_t)B * 3 * cs * cs * 4;
     off = (off + 255) & ~(size_t)255;
+    t.yclip = (float *)(base ? base + off : nullptr);
+    off += ((size_t)B * 3 * cs * cs * 4 + 255) & ~(size_t)255;
+    t.gssim = (float *)(base ? base + off : nullptr);
+    off += ((size_t)B * 3 * cs * cs * 4 + 255) & ~(size_t)255;
+    t.ssim_ws = base ? base + off : nullptr;
+    t.ssim_ws_bytes = nd_ssim_loss_workspace_bytes(B, 3, cs, cs);
+    off += (t.ssim_ws_bytes + 255) & ~(size_t)255;
     t.bytes = off;
     return t;
 }
@@ -444,13 +466,17 @@ extern "C" int nd_utnet_train_workspace_init(void *ws, size_t ws_bytes, int funi
 }
 
 // One training step without the optimizer: packs the weights on the device, runs forward (PReLU only), the loss
-//   loss = w_l1 * mean|clip(y,0,1) - target| + w_mse * mean (clip(y,0,1) - target)^2
+//   loss = w_l1 * mean|g - target| + w_mse * mean (g - target)^2 + w_ssim * mean_n(1 - SSIM_n(g, target))
+//          + w_msssim * mean_n(1 - MS-SSIM_n(g, target)),      g = clip(y, 0, 1)          (nn_common.py:198-199, 226-241)
 // and the backward pass.  params / grads: flat fp32 buffers in state-dict order (nd_utnet_param_range);
 // x, target, y_out: [batch,3,cs,cs] NCHW fp32; loss_out: one float in HBM; blobs: nd_utnet_train_blob_bytes scratch.
 extern "C" int nd_utnet_train_step(int funit, const float *params, float *grads, void *blobs, const float *x,
-                                   const float *target, float *y_out, float w_l1, float w_mse, float *loss_out, int batch,
-                                   int cs, void *ws, size_t ws_bytes, void *stream) {
+                                   const float *target, float *y_out, float w_l1, float w_mse, float w_ssim, float w_msssim,
+                                   float *loss_out, int batch, int cs, void *ws, size_t ws_bytes, void *stream) {
     ND_TRY(check_train(funit, cs, batch));
+    if (w_msssim != 0.f && cs < 161)
+        ND_FAIL(ND_EINVAL, "UtNet training: the MS-SSIM loss needs crops of at least 161 pixels (five scales of an 11-tap window), "
+                           "got %d; the reference fails on them too (pt_losses.py:20-28)", cs);
     if (!params || !grads || !blobs || !x || !target || !y_out || !loss_out || !ws) ND_FAIL(ND_EINVAL, "train step: null pointer");
     TrainPlan t = make_train_plan(funit, cs, batch, (char *)ws);
     if (ws_bytes < t.bytes) ND_FAIL(ND_ENOMEM, "UtNet training workspace: %zu B given, %zu B needed", ws_bytes, t.bytes);
@@ -508,6 +534,18 @@ extern "C" int nd_utnet_train_step(int funit, const float *params, float *grads,
     hipLaunchKernelGGL(k_loss_grad, dim3(lblocks), dim3(256), 0, s, (const float *)y_out, target, nout, w_l1, w_mse, t.gy, t.red);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, (const float *)t.red, lblocks, 1.f / (float)nout, loss_out);
     ND_HIP(hipGetLastError());
+    if (w_ssim != 0.f || w_msssim != 0.f) {
+        hipLaunchKernelGGL(k_clip01, dim3(1024), dim3(256), 0, s, (const float *)y_out, nout, t.yclip);
+        int acc = 0;
+        if (w_ssim != 0.f) {
+            ND_TRY(nd_ssim_loss_grad(t.yclip, target, B, 3, cs, cs, 0, w_ssim, loss_out, t.gssim, acc, t.ssim_ws, t.ssim_ws_bytes, s));
+            acc = 1;
+        }
+        if (w_msssim != 0.f)
+            ND_TRY(nd_ssim_loss_grad(t.yclip, target, B, 3, cs, cs, 1, w_msssim, loss_out, t.gssim, acc, t.ssim_ws, t.ssim_ws_bytes, s));
+        hipLaunchKernelGGL(k_add_clip_grad, dim3(1024), dim3(256), 0, s, (const float *)y_out, (const float *)t.gssim, nout, t.gy);
+        ND_HIP(hipGetLastError());
+    }
 
     // ---- 4. backward
     // final 1x1

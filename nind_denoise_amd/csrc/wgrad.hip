@@ -237,21 +237,19 @@ int nd_launch_wgrad(const QpBuf &A, int a_plane0, int M, const QpBuf &Bq, int b_
     p.nblk = p.Np / 64;
     const int lds = 2 * ((16 + (taps == 9 ? 3 : 1) * 16) * (1024 + 16));
     dim3 grid((p.Mp / 64) * p.nblk, ksplit);
-    if (taps == 9) {
-        static bool set9 = false;
-        if (!set9) {
-            ND_HIP(hipFuncSetAttribute((const void *)k_wgrad<9>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            set9 = true;
-        }
-        hipLaunchKernelGGL(k_wgrad<9>, grid, dim3(768), lds, s, p);
-    } else {
-        static bool set1 = false;
-        if (!set1) {
-            ND_HIP(hipFuncSetAttribute((const void *)k_wgrad<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            set1 = true;
-        }
-        hipLaunchKernelGGL(k_wgrad<1>, grid, dim3(256), lds, s, p);
+    static bool lds_set[16][2] = {{false}};   // per device: function attributes belong to the device's copy of the code object
+    int dev = 0;
+    ND_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) ND_FAIL(ND_EINVAL, "wgrad: device index %d", dev);
+    if (!lds_set[dev][taps == 9]) {
+        const void *fn = taps == 9 ? (const void *)k_wgrad<9> : (const void *)k_wgrad<1>;
+        ND_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        lds_set[dev][taps == 9] = true;
     }
+    if (taps == 9)
+        hipLaunchKernelGGL(k_wgrad<9>, grid, dim3(768), lds, s, p);
+    else
+        hipLaunchKernelGGL(k_wgrad<1>, grid, dim3(256), lds, s, p);
     ND_HIP(hipGetLastError());
     const long total = (long)taps * M * N;
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, partial, ksplit, taps, p.Mp,

@@ -3,8 +3,11 @@ buffers, data parallel over RCCL.
 
 Mirrors the reference's generator update (/root/reference/src/nind_denoise/nn_common.py:163-218 and the loop body of
 nn_train.py:308-380):  generated = model(noisy).clip(0,1);  loss = sum_k weight_k * criterion_k(generated, clean);
-loss.backward();  Adam(lr, betas=(beta1, .999), amsgrad=True).step().   Criteria available here: L1 and MSE (the
-reference's SSIM / MS-SSIM criteria come from piqa, which is not installed in this image).
+loss.backward();  Adam(lr, betas=(beta1, .999), amsgrad=True).step().   Criteria: L1, MSE, SSIM and MSSSIM (the
+reference's SSIM / MS-SSIM criteria come from piqa, which is not installed here: csrc/ssim.hip restates its published
+algorithm, forward and backward -- see oracle/losses.py).  Every criterion is reduced with a mean over the batch; the
+reference builds its criteria with reduction=None and calls .backward() on the per-sample vector, which torch rejects
+for batches larger than one (nn_common.py:170-177, 216), so there is no other reading of "the loss" to reproduce.
 
 The module's parameters are views into ONE flat fp32 buffer in state-dict order; gradients come back in a second flat
 buffer with the same layout, so the data-parallel reduction is one all-reduce and the optimizer one kernel.
@@ -30,9 +33,9 @@ class UtNetTrainer:
         self.lib = _lib.load()
         self.funit = model.funit
         self.weights = {"L1": 0.0, "MSE": 1.0} if weights is None else dict(weights)
-        unknown = set(k for k, v in self.weights.items() if v) - {"L1", "MSE"}
-        if unknown:
-            raise NotImplementedError(f"loss terms {sorted(unknown)} are not available (piqa is not installed)")
+        unknown = set(k for k, v in self.weights.items() if v) - {"L1", "MSE", "SSIM", "MSSSIM"}
+        if unknown:   # D1 / D2: the discriminator terms of the reference's GAN mode (nn_common.py:178-182)
+            raise NotImplementedError(f"loss terms {sorted(unknown)} are not available (generator losses: L1, MSE, SSIM, MSSSIM)")
         self.lr, self.betas, self.eps, self.amsgrad = lr, (beta1, beta2), eps, amsgrad
         self.group = process_group
         n = self.lib.nd_utnet_param_count(self.funit)
@@ -88,6 +91,7 @@ class UtNetTrainer:
             _lib.check(self.lib.nd_utnet_train_step(self.funit, self.flat.data_ptr(), self.grads.data_ptr(),
                                                     self.blobs.data_ptr(), noisy.data_ptr(), clean.data_ptr(), y.data_ptr(),
                                                     float(self.weights.get("L1", 0.0)), float(self.weights.get("MSE", 0.0)),
+                                                    float(self.weights.get("SSIM", 0.0)), float(self.weights.get("MSSSIM", 0.0)),
                                                     self.loss.data_ptr(), batch, cs, ws.data_ptr(), ws.numel(),
                                                     _lib.stream_ptr(self.device)), "nd_utnet_train_step")
         average_gradients(self.grads, self.group)     # RCCL: one flat all-reduce (124 MB for UtNet(64))

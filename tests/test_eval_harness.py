@@ -183,3 +183,26 @@ def test_denoise_dir_end_to_end(dev, tmp_path):
     for fn in ("trainres.json", "testres.json"):
         d = json.load(open(mdir / fn))
         assert abs(d["7"]["test_msssim"] - want["msssim"]) < SCORE_TOL and d["best_epoch"]["test_mse"] == 7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("multiscale,shape", [(False, (2, 3, 40, 57)), (False, (1, 3, 184, 184)), (True, (2, 3, 184, 184)),
+                                                (True, (1, 3, 163, 201)), (True, (1, 1, 330, 169))])
+def test_ssim_losses_backward_vs_oracle_autograd(dev, multiscale, shape):
+    """The scores as training criterions (nn_common.py:170-177): gradient with respect to the generated batch against torch
+    autograd through the oracle, per-sample loss vector weighted like `(loss * weight).mean().backward()`."""
+    from nind_denoise_amd.common.libs import pt_losses
+    x, y = _pair(*shape, seed=shape[3], noise=0.15)
+    wvec = torch.linspace(0.5, 1.5, shape[0])
+    xr = x.clone().requires_grad_()
+    lref = 1 - (olosses.ms_ssim(xr, y) if multiscale else olosses.ssim(xr, y))
+    (lref * wvec).mean().backward()
+    xd = x.to(dev).requires_grad_()
+    crit = pt_losses.MS_SSIM_loss() if multiscale else pt_losses.SSIM_loss()
+    l = crit(xd, y.to(dev))
+    (l * wvec.to(dev)).mean().backward()
+    assert (l.detach().cpu() - lref.detach()).abs().max().item() < SCORE_TOL
+    g, gref = xd.grad.cpu(), xr.grad
+    scale = gref.abs().max().item()
+    err = (g - gref).abs().max().item() / scale
+    assert torch.isfinite(g).all() and err < 2e-4, (err, scale)

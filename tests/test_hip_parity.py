@@ -773,13 +773,18 @@ def test_weight_gradient_vs_autograd(dev, case):
         assert err <= 2e-5 * max(ref.abs().max().item(), 1.0) + 1e-5, (case, what, err, ref.abs().max().item())
 
 
-def _autograd_reference(sd, x, t, w_l1, w_mse, dtype=torch.float32):
+def _autograd_reference(sd, x, t, w_l1, w_mse, dtype=torch.float32, w_ssim=0.0, w_msssim=0.0):
+    from oracle import losses as olosses
     from oracle import networks as onet
     params = {k: v.clone().to(dtype).requires_grad_() for k, v in sd.items()}
     x, t = x.to(dtype), t.to(dtype)
     y = onet.utnet_forward(params, x)
     g = y.clip(0, 1)
     loss = w_l1 * F.l1_loss(g, t) + w_mse * F.mse_loss(g, t)
+    if w_ssim:
+        loss = loss + w_ssim * (1 - olosses.ssim(g, t)).mean()
+    if w_msssim:
+        loss = loss + w_msssim * (1 - olosses.ms_ssim(g, t)).mean()
     loss.backward()
     return y.detach(), loss.detach(), params
 
@@ -818,6 +823,62 @@ def test_training_step_gradients_vs_autograd(dev, funit, cs, B, w_l1, w_mse):
         bar = 2e-3 + (10 * (params32[name].grad - ref).abs().max().item() / scale if wide else 0.0)
         assert torch.isfinite(got).all() and err <= bar, (name, err, bar, scale)
     print(f"training step f{funit} cs{cs}: worst relative gradient error {worst:.2e}")
+
+
+@pytest.mark.parametrize("cs,weights", [(120, {"SSIM": 1.0}), (168, {"MSSSIM": 1.0}),
+                                        (184, {"L1": 0.2, "MSE": 0.2, "SSIM": 0.2, "MSSSIM": 0.4})])
+def test_training_step_ssim_losses_vs_autograd(dev, cs, weights):
+    # the reference's default generator loss is MS-SSIM (weights {'MSSSIM': 1}): network gradients through the HIP SSIM /
+    # MS-SSIM backward against torch autograd through the oracle network + oracle scores
+    from nind_denoise_amd.networks.UtNet import UtNet
+    from nind_denoise_amd.train import UtNetTrainer
+    funit, B = 8, 2
+    sd = synth.make_utnet_state_dict(funit=funit, seed=17, gain=1.8)
+    net = UtNet(funit=funit)
+    net.load_state_dict(sd)
+    tr = UtNetTrainer(net, device=dev, weights=weights)
+    g = torch.Generator().manual_seed(5)
+    # image-like input; the target is the (random-weight) network's own output plus noise, so that generated and target
+    # batches are correlated: on unrelated images some coarse-scale cs is <= 0 and MS-SSIM's relu kills the whole gradient
+    from oracle import networks as onet
+    x = F.interpolate(torch.rand(B, 3, cs // 8, cs // 8, generator=g), size=(cs, cs), mode="bilinear", align_corners=False)
+    x = (0.8 * x + 0.1 + 0.05 * torch.randn(B, 3, cs, cs, generator=g)).clip(0, 1)
+    with torch.no_grad():
+        y0 = onet.utnet_forward(sd, x)
+    y0 = (y0 - y0.mean()) / (4 * y0.std()) + 0.5            # bring the output into [0, 1] territory: scale the last layer
+    sd = dict(sd)
+    with torch.no_grad():
+        k = 1.0 / (4 * onet.utnet_forward(sd, x).std())
+        sd["tconvs4.4.bias"] = (sd["tconvs4.4.bias"] - onet.utnet_forward(sd, x).mean()) * k + 0.5
+        sd["tconvs4.4.weight"] = sd["tconvs4.4.weight"] * k
+    net.load_state_dict(sd)
+    tr = UtNetTrainer(net, device=dev, weights=weights)
+    # (+0.02: a brightness offset, else the last bias' gradient -- the response to a global shift -- hinges on the sample
+    # mean of the noise and is ill-conditioned against 1e-6 differences of the two forward passes)
+    t = (y0 + 0.02 + 0.03 * torch.randn(B, 3, cs, cs, generator=g)).clip(0, 1)
+    y, loss = tr.forward_backward(x, t)
+    torch.cuda.synchronize()
+    kw = dict(w_ssim=weights.get("SSIM", 0.0), w_msssim=weights.get("MSSSIM", 0.0))
+    y_ref, loss_ref, params = _autograd_reference(sd, x, t, weights.get("L1", 0.0), weights.get("MSE", 0.0), torch.float64, **kw)
+    params32 = _autograd_reference(sd, x, t, weights.get("L1", 0.0), weights.get("MSE", 0.0), **kw)[2]
+    assert_close(y, y_ref.float(), "training forward")
+    assert abs(loss.item() - loss_ref.item()) <= 2e-5 * max(1.0, abs(loss_ref.item())), (loss.item(), loss_ref.item())
+    worst = 0.0
+    gmax = max(p.grad.abs().max().item() for p in params.values())
+    assert gmax > 1e-4                                                        # a real gradient, not the relu-dead case
+    for name, p in params.items():
+        got, ref = tr.grad_of(name).cpu(), p.grad.float()
+        scale = max(ref.abs().max().item(), 1e-8)
+        err = (got - ref).abs().max().item() / scale
+        worst = max(worst, err)
+        # reference = float64 autograd; bar tied to what fp32 autograd itself loses on the same tensor: the SSIM gradient
+        # oscillates in sign from pixel to pixel, so whole-image sums (PReLU slopes, biases) keep few digits in fp32
+        bar = 2e-3 + 10 * (params32[name].grad - ref).abs().max().item() / scale
+        assert torch.isfinite(got).all() and err <= bar, (name, err, bar, scale)
+    print(f"training step {weights} cs{cs}: worst relative gradient error {worst:.2e}")
+    if "MSSSIM" in weights:
+        with pytest.raises(ValueError, match="161"):     # the 128 / 136-pixel crops of BASELINE config 5 cannot use MS-SSIM
+            tr.forward_backward(x[..., :136, :136].contiguous(), t[..., :136, :136].contiguous())
 
 
 def test_adam_amsgrad_two_steps_vs_torch(dev):

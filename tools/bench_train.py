@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--funit", type=int, default=64)
+    ap.add_argument("--loss", default="L1=0.5,MSE=0.5", help="criterion weights, e.g. MSSSIM=1 (the reference's default; needs "
+                                                               "crops >= 161) or SSIM=0.5,L1=0.5")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -41,7 +43,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     net = UtNet(funit=args.funit)
     net.load_state_dict(synth.make_utnet_state_dict(args.funit, seed=123))
-    tr = UtNetTrainer(net, lr=1e-4, beta1=0.75, device=dev, weights={"L1": 0.5, "MSE": 0.5})
+    weights = {k: float(v) for k, v in (kv.split("=") for kv in args.loss.split(","))}
+    tr = UtNetTrainer(net, lr=1e-4, beta1=0.75, device=dev, weights=weights)
     if world > 1:
         dist.broadcast(tr.flat, src=0)
     g = torch.Generator().manual_seed(100 + rank)
@@ -72,7 +75,7 @@ def main():
                           "unit": "crops/s", "n_gpus": world, "ms_per_step": round(1e3 * dt / args.steps, 2),
                           "scaling": "weak", "dtype": "f32", "data": "synthetic",
                           "config": {"workload": f"UtNet({args.funit},PReLU) fwd+bwd+Adam(amsgrad), crop {args.cs}, "
-                                                 f"per-GPU batch {args.batch}", "forward_flop_per_crop": fwd},
+                                                 f"per-GPU batch {args.batch}, loss {args.loss}", "forward_flop_per_crop": fwd},
                           "approx_tflops": round(3 * fwd * samples / dt / 1e12, 2), "loss": float(loss.item())}))
     if world > 1:
         dist.destroy_process_group()
