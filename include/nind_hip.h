@@ -204,6 +204,15 @@ size_t nd_ssim_loss_workspace_bytes(int n, int c, int h, int w);
 int nd_ssim_loss_grad(const float *x, const float *y, int n, int c, int h, int w, int multiscale, float weight,
                       float *loss_acc, float *gx, int accumulate, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- Winograd F(t x t, 3 x 3), t = 2 | 4: fp32 inference form of the wide 3x3 layers (same math as nd_layer_forward on a
+ * CONV3 / CONVT3 layer, re-associated: results agree to ~1e-6 (t = 2) / ~1e-5 (t = 4) relative).  Cin % 16 == 0. */
+size_t nd_winograd_packed_bytes(int tile, int cin, int cout);
+int nd_winograd_pack(int tile, int kind, int cin, int cout, const float *w, const float *bias, void *packed,
+                     size_t packed_bytes);
+size_t nd_layer_winograd_workspace_bytes(int tile, int kind, int batch, int cin, int cout, int h, int w);
+int nd_layer_forward_winograd(int tile, int kind, int act, float slope, const void *packed, const float *x, int batch,
+                              int cin, int h, int w, int cout, float *y, void *workspace, size_t workspace_bytes, void *stream);
+
 /* Kernel micro-benchmark: `iters` launches of one conv layer (variant -1 = automatic choice) on pseudo-random
  * quad-planar data carved from `workspace` (nd_layer_workspace_bytes + nd_layer_packed_bytes + 256 B); mean launch
  * duration from HIP events on `stream`.  Synchronises the stream. */

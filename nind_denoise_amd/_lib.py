@@ -59,6 +59,11 @@ _SIGNATURES = {
     "nd_layer_workspace_bytes": (c_size_t, [c_int] * 7),
     "nd_layer_forward": (c_int, [c_int, c_int, c_float, c_int, c_void_p, c_void_p] + [c_int] * 5
                          + [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "nd_winograd_packed_bytes": (c_size_t, [c_int] * 3),
+    "nd_winograd_pack": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_size_t]),
+    "nd_layer_winograd_workspace_bytes": (c_size_t, [c_int] * 7),
+    "nd_layer_forward_winograd": (c_int, [c_int, c_int, c_int, c_float, c_void_p, c_void_p] + [c_int] * 5
+                                  + [c_void_p, c_void_p, c_size_t, c_void_p]),
     "nd_maxpool2_forward": (c_int, [c_void_p] + [c_int] * 4 + [c_void_p, c_void_p, c_size_t, c_void_p]),
     "nd_layer_wgrad_workspace_bytes": (c_size_t, [c_int] * 6),
     "nd_layer_wgrad": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

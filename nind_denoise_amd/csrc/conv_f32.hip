@@ -8,7 +8,10 @@ static const Variant g_f32_group[kGroup] = {ND_VARIANT_GROUP(ND_F32, "f32")};
 static const Variant g_f32_extra[] = {
     ND_VARIANT(ND_F32, "f32", 2, 2, 2, 4, 9, 1, false, 3),  // M128 x N256, 8 waves, 3 stages
     ND_VARIANT(ND_F32, "f32", 2, 2, 1, 4, 9, 1, false, 3),  // M64  x N256, 4 waves, 3 stages
+    ND_VARIANT(ND_F32, "f32", 2, 4, 4, 2, 1, 2, false, 3),  // 1 tap, M256 x N256 (64x128 per wave): the Winograd GEMMs (Cout % 256 == 0)
+    ND_VARIANT(ND_F32, "f32", 2, 2, 2, 4, 1, 2, false, 3),  // 1 tap, M128 x N256
 };
+constexpr int kVariantGemm256 = 3 * kGroup + 2, kVariantGemm128 = 3 * kGroup + 3;
 constexpr int kExtra = (int)(sizeof(g_f32_extra) / sizeof(g_f32_extra[0]));
 static const int g_nvariants = 3 * kGroup + kExtra;
 // variant index: [f32 group][bf16 group][f16 group][fp32-only experiments]
@@ -21,6 +24,7 @@ static const Variant &variant_at(int v) {
 
 
 int nd_conv_variant_count() { return g_nvariants; }
+int nd_conv_variant_gemm(int rows) { return rows == 256 ? kVariantGemm256 : kVariantGemm128; }
 const char *nd_conv_variant_label(int v) { return (v >= 0 && v < g_nvariants) ? variant_at(v).name : ""; }
 
 // Largest input span (pixels) of one N tile + 3x3 halo.  cross = tiles may run across image boundaries.
@@ -71,10 +75,12 @@ static const size_t kMaxLds = 160 * 1024;
 // grid: (split tiles, MBLK/4 channel quads)
 __global__ __launch_bounds__(256) void k_split_finish(ConvParams p, int mblk, int nblk, int up, int dt) {
     const int t = blockIdx.x, quad = blockIdx.y;
-    const int id = p.split_first + t;
+    const int gid = p.split_first + t;
+    const int z = gid / p.tiles_per_problem, id = gid - z * p.tiles_per_problem;
     const int nb = id / p.n_tiles_m, mb = id - nb * p.n_tiles_m;
     const int m4 = mb * mblk + quad * 4;
     if (m4 >= p.M) return;
+    p.out += z * p.out_bs;
     const float slope = p.act == ND_ACT_NONE ? 1.f : (p.slope_dev ? *p.slope_dev : p.slope);
     const f32x4 bv = *(const f32x4 *)(p.bias + m4);
     const int nq = mblk / 4;
@@ -297,7 +303,12 @@ int nd_launch_conv(const ConvDesc &d, hipStream_t stream) {
         p.n_tiles_n = p.tpi * p.nimg;
     }
     p.n_tiles_m = (M + V.mblk - 1) / V.mblk;
-    const long ntiles = (long)p.n_tiles_n * p.n_tiles_m;
+    p.tiles_per_problem = p.n_tiles_n * p.n_tiles_m;
+    p.in_bs = d.in_bs;
+    p.out_bs = d.out_bs;
+    p.w_bs = (long)d.w_bs;
+    if (d.nbatch > 1 && d.pre) ND_FAIL(ND_EINVAL, "conv: a batched launch keeps no pre-activation copy");
+    const long ntiles = (long)p.tiles_per_problem * (d.nbatch > 1 ? d.nbatch : 1);
     const int per_cu = lds * 2 <= kMaxLds && V.threads <= 256 ? 2 : 1;
     const long slots = (long)g_num_cus * per_cu;
     const long cap = d.part && g_split_on ? (long)(d.part_bytes / ((size_t)V.mblk * V.nblk * 4)) : 0;

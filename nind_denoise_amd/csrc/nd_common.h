@@ -65,12 +65,21 @@ struct ConvDesc {
     long pre_plane = 0;     // 16-byte elements per plane of `pre`
     float *part = nullptr;  // scratch for the split-K tail (raw accumulators of K slices); null: never split
     size_t part_bytes = 0;
+    int nbatch = 1;         // independent problems of this shape in one launch (Winograd positions)
+    long in_bs = 0, out_bs = 0;   // 16-byte elements between consecutive problems' input / output buffers
+    size_t w_bs = 0;        // floats between consecutive problems' packed weights (the bias is shared)
 };
 // scratch that lets every layer split its partial round: 512 work items of 64 x 1024 accumulators
 static const size_t kSplitScratchBytes = (size_t)512 * 64 * 1024 * 4;
 int nd_launch_conv(const ConvDesc &d, hipStream_t stream);
 static inline int nd_launch_conv_f32(const ConvDesc &d, hipStream_t stream) { return nd_launch_conv(d, stream); }
 int nd_conv_variant_count();
+int nd_conv_variant_gemm(int rows);   // 1-tap fp32 variant with a 256- or 128-row workgroup tile (Winograd GEMMs)
+// Winograd F(T x T, 3 x 3), T = 2 | 4 (winograd.hip): fp32 inference path of the wide 3x3 layers
+size_t nd_wino_packed_floats(int T, int cin, int cout);
+int nd_wino_pack(int T, int kind, int cin, int cout, const float *w, const float *bias, float *packed);
+size_t nd_wino_scratch_bytes(int T, const QpBuf &in, int cin, int cout);
+int nd_launch_conv_wino(int T, const ConvDesc &d, void *scratch, size_t scratch_bytes, hipStream_t s);
 const char *nd_conv_variant_label(int v);
 
 // packed size helpers (host)

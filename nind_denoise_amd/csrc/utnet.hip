@@ -287,6 +287,54 @@ extern "C" int nd_layer_forward(int kind, int act, float slope, int dtype, const
     return ND_OK;
 }
 
+// Winograd form of a 3x3 layer (tile = 2 | 4): same interface as nd_layer_forward with a blob from nd_winograd_pack
+extern "C" size_t nd_winograd_packed_bytes(int tile, int cin, int cout) {
+    if ((tile != 2 && tile != 4) || cin <= 0 || cout <= 0) return 0;
+    return nd_wino_packed_floats(tile, cin, cout) * sizeof(float);
+}
+extern "C" int nd_winograd_pack(int tile, int kind, int cin, int cout, const float *w, const float *bias, void *packed,
+                                size_t packed_bytes) {
+    const size_t need = nd_winograd_packed_bytes(tile, cin, cout);
+    if (!need) ND_FAIL(ND_EINVAL, "nd_winograd_pack: bad shape");
+    if (!packed || packed_bytes < need) ND_FAIL(ND_ENOMEM, "nd_winograd_pack: %zu B given, %zu B needed", packed_bytes, need);
+    return nd_wino_pack(tile, kind, cin, cout, w, bias, (float *)packed);
+}
+extern "C" size_t nd_layer_winograd_workspace_bytes(int tile, int kind, int batch, int cin, int cout, int h, int w) {
+    if ((tile != 2 && tile != 4) || (kind != ND_CONV3 && kind != ND_CONVT3)) return 0;
+    const size_t base = nd_layer_workspace_bytes(kind, batch, cin, cout, h, w, ND_F32);
+    if (!base) return 0;
+    const LayerPlan pl = layer_plan(kind, batch, cin, cout, h, w, nullptr, ND_F32);
+    return base + nd_wino_scratch_bytes(tile, pl.in, cin, cout);
+}
+extern "C" int nd_layer_forward_winograd(int tile, int kind, int act, float slope, const void *packed, const float *x, int batch,
+                                         int cin, int h, int w, int cout, float *y, void *ws, size_t ws_bytes, void *stream) {
+    const size_t need = nd_layer_winograd_workspace_bytes(tile, kind, batch, cin, cout, h, w);
+    if (!need) ND_FAIL(ND_EINVAL, "nd_layer_forward_winograd: bad shape / kind / tile");
+    if (!ws || ws_bytes < need) ND_FAIL(ND_ENOMEM, "nd_layer_forward_winograd: workspace %zu B given, %zu B needed", ws_bytes, need);
+    hipStream_t s = (hipStream_t)stream;
+    LayerPlan pl = layer_plan(kind, batch, cin, cout, h, w, (char *)ws, ND_F32);
+    ND_HIP(hipMemsetAsync(ws, 0, pl.bytes, s));
+    ND_TRY(nd_launch_nchw_to_qp(x, cin, pl.in, 0, s));
+    ConvDesc d;
+    d.kind = kind;
+    d.act = act;
+    d.slope = slope;
+    d.slope_dev = nullptr;
+    d.cin = cin;
+    d.cout = cout;
+    d.wpk = (const float *)packed;
+    d.bias = nullptr;
+    d.in = pl.in;
+    d.out = pl.out;
+    d.out_plane0 = 0;
+    d.variant = -1;
+    d.part = pl.split;
+    d.part_bytes = kSplitScratchBytes;
+    ND_TRY(nd_launch_conv_wino(tile, d, (char *)ws + pl.bytes, ws_bytes - pl.bytes, s));
+    ND_TRY(nd_launch_qp_to_nchw(pl.out, 0, y, cout, s));
+    return ND_OK;
+}
+
 extern "C" int nd_maxpool2_forward(const float *x, int batch, int c, int h, int w, float *y, void *ws, size_t ws_bytes,
                                    void *stream) {
     if (batch <= 0 || c <= 0 || h < 2 || w < 2) ND_FAIL(ND_EINVAL, "nd_maxpool2_forward: bad shape");

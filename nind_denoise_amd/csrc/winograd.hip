@@ -1,0 +1,288 @@
+// Winograd F(T x T, 3 x 3) for the wide 3x3 layers (inference, fp32): T = 2 (16 positions, 2.25x fewer MACs) or T = 4 (36 positions,
+// 4x fewer).  Reference op: the Conv2d(3) / ConvTranspose2d(3) layers of networks/UtNet.py:27-88; same math, other association:
+//     Y = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A        per (T+2) x (T+2) input tile d -> T x T output tile Y
+// Three passes over HBM, because a fused kernel does not fit the LDS / register budget of one CU:
+//   1. k_wino_input   X (quad-planar, bordered)            -> V[pos][Cin/4][tile]   (HBM-bound: reads X once, writes (T+2)^2/T^2 x |X|)
+//   2. conv_qp 1-tap  P = (T+2)^2 independent GEMMs in ONE launch: M[pos] = U[pos] (Cout x Cin) * V[pos]   (MFMA-bound)
+//   3. k_wino_output  M[pos][Cout/4][tile] -> A^T m A + bias, activation -> destination buffer (HBM-bound)
+// It pays where channels are wide: pass 1 + 3 move ~2 (T+2)^2/T^2 x (|X| + |Y|) bytes, pass 2 saves 9 T^2/(T+2)^2 of the MFMAs.
+// ConvTranspose2d(3) is the same valid correlation on its zero-bordered input with flipped / transposed weights (as in pack.hip).
+#include <vector>
+
+#include "nd_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+template <int T> struct Wino;
+template <> struct Wino<2> {
+    static constexpr int A = 4;
+    template <typename V> __host__ __device__ static void bt(const V *d, V *o) {   // B^T d
+        o[0] = d[0] - d[2];
+        o[1] = d[1] + d[2];
+        o[2] = d[2] - d[1];
+        o[3] = d[1] - d[3];
+    }
+    template <typename V> __host__ __device__ static void at(const V *m, V *o) {   // A^T m
+        o[0] = m[0] + m[1] + m[2];
+        o[1] = m[1] - m[2] - m[3];
+    }
+    static void g(const double *w, double *o) {   // G g
+        o[0] = w[0];
+        o[1] = 0.5 * (w[0] + w[1] + w[2]);
+        o[2] = 0.5 * (w[0] - w[1] + w[2]);
+        o[3] = w[2];
+    }
+};
+template <> struct Wino<4> {
+    static constexpr int A = 6;
+    template <typename V> __host__ __device__ static void bt(const V *d, V *o) {
+        o[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+        o[1] = -4.f * (d[1] + d[2]) + d[3] + d[4];
+        o[2] = 4.f * (d[1] - d[2]) - d[3] + d[4];
+        o[3] = -2.f * d[1] - d[2] + 2.f * d[3] + d[4];
+        o[4] = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
+        o[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+    }
+    template <typename V> __host__ __device__ static void at(const V *m, V *o) {
+        o[0] = m[0] + m[1] + m[2] + m[3] + m[4];
+        o[1] = m[1] - m[2] + 2.f * (m[3] - m[4]);
+        o[2] = m[1] + m[2] + 4.f * (m[3] + m[4]);
+        o[3] = m[1] - m[2] + 8.f * (m[3] - m[4]) + m[5];
+    }
+    static void g(const double *w, double *o) {
+        o[0] = w[0] / 4;
+        o[1] = -(w[0] + w[1] + w[2]) / 6;
+        o[2] = -(w[0] - w[1] + w[2]) / 6;
+        o[3] = w[0] / 24 + w[1] / 12 + w[2] / 6;
+        o[4] = w[0] / 24 - w[1] / 12 + w[2] / 6;
+        o[5] = w[2];
+    }
+};
+
+// V[pos][plane][tile] = B^T d B.  grid (ceil(tiles / 256), planes)
+template <int T>
+__global__ __launch_bounds__(256) void k_wino_input(const f32x4 *__restrict__ x, long xnp, int Hb, int Wb, int B, int TY, int TX,
+                                                    f32x4 *__restrict__ v, long vnp, long vbs) {
+    constexpr int A = Wino<T>::A;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const long tiles = (long)B * TY * TX;
+    if (t >= tiles) return;
+    const int q = blockIdx.y;
+    const int tx = (int)(t % TX), ty = (int)((t / TX) % TY), b = (int)(t / ((long)TX * TY));
+    const f32x4 *src = x + (long)q * xnp + ((long)b * Hb + T * ty) * Wb + T * tx;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 d[A][A], r[A][A];
+#pragma unroll
+    for (int i = 0; i < A; ++i)
+#pragma unroll
+        for (int j = 0; j < A; ++j) d[i][j] = (T * ty + i < Hb && T * tx + j < Wb) ? src[(long)i * Wb + j] : zero;
+    // columns: r[:, j] = B^T d[:, j]
+#pragma unroll
+    for (int j = 0; j < A; ++j) {
+        f32x4 c[A], o[A];
+#pragma unroll
+        for (int i = 0; i < A; ++i) c[i] = d[i][j];
+        Wino<T>::bt(c, o);
+#pragma unroll
+        for (int i = 0; i < A; ++i) r[i][j] = o[i];
+    }
+    // rows: V[i, :] = B^T r[i, :]   (= r B)
+    f32x4 *dst = v + (long)q * vnp + t;
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+        f32x4 o[A];
+        Wino<T>::bt(r[i], o);
+#pragma unroll
+        for (int j = 0; j < A; ++j) dst[(long)(i * A + j) * vbs] = o[j];
+    }
+}
+
+// out = act(A^T m A + bias).  grid (ceil(tiles / 256), Cout / 4)
+template <int T>
+__global__ __launch_bounds__(256) void k_wino_output(const f32x4 *__restrict__ m, long mnp, long mbs, int B, int TY, int TX, int Hv,
+                                                     int Wv, const float *__restrict__ bias, int act, float slope_imm,
+                                                     const float *__restrict__ slope_dev, f32x4 *__restrict__ out, long onp,
+                                                     int out_plane0, int Ho, int Wo, int opad) {
+    constexpr int A = Wino<T>::A;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const long tiles = (long)B * TY * TX;
+    if (t >= tiles) return;
+    const int q = blockIdx.y;
+    const int tx = (int)(t % TX), ty = (int)((t / TX) % TY), b = (int)(t / ((long)TX * TY));
+    const f32x4 *src = m + (long)q * mnp + t;
+    f32x4 r[A][T];
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+        f32x4 row[A];
+#pragma unroll
+        for (int j = 0; j < A; ++j) row[j] = src[(long)(i * A + j) * mbs];
+        Wino<T>::at(row, r[i]);   // m A  (row-wise A^T)
+    }
+    const f32x4 bv = *(const f32x4 *)(bias + 4 * q);
+    const float slope = act == ND_ACT_NONE ? 1.f : (slope_dev ? *slope_dev : slope_imm);
+    f32x4 *dst = out + (long)(out_plane0 + q) * onp + ((long)b * Ho + T * ty + opad) * Wo + T * tx + opad;
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        f32x4 c[A], o[T];
+#pragma unroll
+        for (int i = 0; i < A; ++i) c[i] = r[i][j];
+        Wino<T>::at(c, o);
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            if (T * ty + i >= Hv || T * tx + j >= Wv) continue;
+            f32x4 y = o[i] + bv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float u = y[e];
+                switch (act) {
+                    case ND_ACT_ELU: y[e] = u > 0.f ? u : expm1f(u); break;
+                    case ND_ACT_HARDSWISH: y[e] = u * fminf(fmaxf(u + 3.f, 0.f), 6.f) / 6.f; break;
+                    default: y[e] = u > 0.f ? u : u * slope; break;   // PReLU; "none" is slope 1
+                }
+            }
+            dst[(long)i * Wo + j] = y;
+        }
+    }
+}
+
+int positions(int T) { return (T + 2) * (T + 2); }
+size_t gemm_floats(int cin, int cout) { return nd_packed_floats(ND_CONV1, cin, cout, ND_F32); }
+
+struct WinoGeo {
+    int TY, TX, Hv, Wv;
+    long tiles;          // B * TY * TX
+    long vnp, mnp;       // plane strides (16-byte elements, with slack for the GEMM's DMA over-read)
+    long vbs, mbs;       // position strides
+    size_t v_bytes, m_bytes;
+};
+WinoGeo wino_geo(int T, const QpBuf &in, int cin, int cout) {
+    WinoGeo g;
+    g.Hv = in.Hb - 2;
+    g.Wv = in.Wb - 2;
+    g.TY = (g.Hv + T - 1) / T;
+    g.TX = (g.Wv + T - 1) / T;
+    g.tiles = (long)in.B * g.TY * g.TX;
+    g.vnp = g.mnp = g.tiles;
+    const long slack = 4096;
+    g.vbs = (long)(2 * nd_kblocks(cin)) * g.vnp + slack;
+    g.mbs = (long)((cout + 3) / 4) * g.mnp + slack;
+    g.v_bytes = (size_t)positions(T) * g.vbs * 16;
+    g.m_bytes = (size_t)positions(T) * g.mbs * 16;
+    return g;
+}
+}  // namespace
+
+// ------------------------------------------------------------------ packing (host)
+// layout: P x [1-tap packed GEMM weights U_pos (pack.hip layout, zero bias)] + bias[cout rounded up to 4]
+size_t nd_wino_packed_floats(int T, int cin, int cout) {
+    return (size_t)positions(T) * gemm_floats(cin, cout) + (size_t)(cout + 3) / 4 * 4;
+}
+
+// w: torch layout of the layer (Conv2d: [cout][cin][3][3]; ConvTranspose2d: [cin][cout][3][3]); bias may be null
+int nd_wino_pack(int T, int kind, int cin, int cout, const float *w, const float *bias, float *packed) {
+    if (T != 2 && T != 4) ND_FAIL(ND_EINVAL, "winograd: tile must be 2 or 4");
+    if (kind != ND_CONV3 && kind != ND_CONVT3) ND_FAIL(ND_EINVAL, "winograd: 3x3 layers only");
+    const int A = T + 2, P = A * A;
+    std::vector<float> u((size_t)P * cout * cin);
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci) {
+            double g[3][3], tmp[6][3], U[6][6];
+            for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx)
+                    g[ky][kx] = kind == ND_CONV3 ? w[(((size_t)co * cin + ci) * 3 + ky) * 3 + kx]
+                                                 : w[(((size_t)ci * cout + co) * 3 + (2 - ky)) * 3 + (2 - kx)];
+            for (int kx = 0; kx < 3; ++kx) {   // columns: tmp[:, kx] = G g[:, kx]
+                double c[3] = {g[0][kx], g[1][kx], g[2][kx]}, o[6];
+                if (T == 2) Wino<2>::g(c, o); else Wino<4>::g(c, o);
+                for (int i = 0; i < A; ++i) tmp[i][kx] = o[i];
+            }
+            for (int i = 0; i < A; ++i) {      // rows: U[i, :] = G tmp[i, :]
+                double o[6];
+                if (T == 2) Wino<2>::g(tmp[i], o); else Wino<4>::g(tmp[i], o);
+                for (int j = 0; j < A; ++j) U[i][j] = o[j];
+            }
+            for (int i = 0; i < A; ++i)
+                for (int j = 0; j < A; ++j) u[((size_t)(i * A + j) * cout + co) * cin + ci] = (float)U[i][j];
+        }
+    const size_t gf = gemm_floats(cin, cout);
+    for (int p = 0; p < P; ++p) nd_pack_layer(ND_CONV1, cin, cout, ND_F32, u.data() + (size_t)p * cout * cin, nullptr, packed + p * gf);
+    float *b = packed + (size_t)P * gf;
+    for (int co = 0; co < (cout + 3) / 4 * 4; ++co) b[co] = (bias && co < cout) ? bias[co] : 0.f;
+    return ND_OK;
+}
+
+// ------------------------------------------------------------------ launch
+size_t nd_wino_scratch_bytes(int T, const QpBuf &in, int cin, int cout) {
+    const WinoGeo g = wino_geo(T, in, cin, cout);
+    return ((g.v_bytes + 255) & ~(size_t)255) + ((g.m_bytes + 255) & ~(size_t)255);
+}
+
+// d: the layer as for nd_launch_conv (kind CONV3 / CONVT3, fp32); d.wpk = nd_wino_pack blob.  scratch: nd_wino_scratch_bytes
+int nd_launch_conv_wino(int T, const ConvDesc &d, void *scratch, size_t scratch_bytes, hipStream_t s) {
+    if (T != 2 && T != 4) ND_FAIL(ND_EINVAL, "winograd: tile must be 2 or 4");
+    if ((d.kind != ND_CONV3 && d.kind != ND_CONVT3) || d.in.dt != ND_F32 || d.out.dt != ND_F32)
+        ND_FAIL(ND_EINVAL, "winograd: fp32 3x3 layers only");
+    if (d.cin % 16 || d.cout % 4) ND_FAIL(ND_EINVAL, "winograd: Cin must be a multiple of 16, Cout of 4 (got %d, %d)", d.cin, d.cout);
+    if (d.pre) ND_FAIL(ND_EINVAL, "winograd: inference only (no pre-activation copy)");
+    const WinoGeo g = wino_geo(T, d.in, d.cin, d.cout);
+    if (d.out.Hb != g.Hv + 2 * d.out.pad || d.out.Wb != g.Wv + 2 * d.out.pad || d.out.B != d.in.B)
+        ND_FAIL(ND_EINVAL, "winograd: destination does not fit the result");
+    const size_t need = nd_wino_scratch_bytes(T, d.in, d.cin, d.cout);
+    if (!scratch || scratch_bytes < need) ND_FAIL(ND_ENOMEM, "winograd: scratch %zu B given, %zu B needed", scratch_bytes, need);
+    const int P = positions(T);
+    f32x4 *v = (f32x4 *)scratch;
+    f32x4 *m = (f32x4 *)((char *)scratch + ((g.v_bytes + 255) & ~(size_t)255));
+    const int in_planes = 2 * nd_kblocks(d.cin), out_planes = d.cout / 4;
+    const f32x4 *x = (const f32x4 *)d.in.base + (long)d.in_plane0 * d.in.np();
+    dim3 gi((unsigned)((g.tiles + 255) / 256), in_planes);
+    if (T == 2)
+        hipLaunchKernelGGL(k_wino_input<2>, gi, dim3(256), 0, s, x, d.in.np(), d.in.Hb, d.in.Wb, d.in.B, g.TY, g.TX, v, g.vnp, g.vbs);
+    else
+        hipLaunchKernelGGL(k_wino_input<4>, gi, dim3(256), 0, s, x, d.in.np(), d.in.Hb, d.in.Wb, d.in.B, g.TY, g.TX, v, g.vnp, g.vbs);
+    ND_HIP(hipGetLastError());
+
+    ConvDesc e;
+    e.kind = ND_CONV1;
+    e.act = ND_ACT_NONE;
+    e.slope = 1.f;
+    e.slope_dev = nullptr;
+    e.cin = d.cin;
+    e.cout = d.cout;
+    e.wpk = d.wpk;
+    e.bias = d.wpk + (size_t)nd_mtiles(ND_CONV1, d.cout) * nd_kblocks(d.cin) * 256;   // the zero bias of position 0
+    e.in.base = (float *)v;
+    e.in.planes = in_planes;
+    e.in.B = d.in.B;
+    e.in.Hb = g.TY;
+    e.in.Wb = g.TX;
+    e.in.pad = 0;
+    e.in.pstride = g.vnp;
+    e.in.dt = ND_F32;
+    e.out = e.in;
+    e.out.base = (float *)m;
+    e.out.planes = out_planes;
+    e.out.pstride = g.mnp;
+    e.out_plane0 = 0;
+    e.variant = d.cout % 256 == 0 ? nd_conv_variant_gemm(256) : (d.cout % 128 == 0 ? nd_conv_variant_gemm(128) : -1);
+    e.part = d.part;
+    e.part_bytes = d.part_bytes;
+    e.nbatch = P;
+    e.in_bs = g.vbs;
+    e.out_bs = g.mbs;
+    e.w_bs = gemm_floats(d.cin, d.cout);
+    ND_TRY(nd_launch_conv(e, s));
+
+    const float *bias = d.wpk + (size_t)P * gemm_floats(d.cin, d.cout);
+    dim3 go((unsigned)((g.tiles + 255) / 256), out_planes);
+    f32x4 *out = (f32x4 *)d.out.base;
+    if (T == 2)
+        hipLaunchKernelGGL(k_wino_output<2>, go, dim3(256), 0, s, (const f32x4 *)m, g.mnp, g.mbs, d.in.B, g.TY, g.TX, g.Hv, g.Wv, bias,
+                           d.act, d.slope, d.slope_dev, out, d.out.np(), d.out_plane0, d.out.Hb, d.out.Wb, d.out.pad);
+    else
+        hipLaunchKernelGGL(k_wino_output<4>, go, dim3(256), 0, s, (const f32x4 *)m, g.mnp, g.mbs, d.in.B, g.TY, g.TX, g.Hv, g.Wv, bias,
+                           d.act, d.slope, d.slope_dev, out, d.out.np(), d.out_plane0, d.out.Hb, d.out.Wb, d.out.pad);
+    ND_HIP(hipGetLastError());
+    return ND_OK;
+}

@@ -176,6 +176,51 @@ def test_layer_split_k(dev, case, dtype):
         assert (y_on - y_off).abs().max().item() <= tol
 
 
+WINO_CASES = [
+    # kind, B, cin, cout, H, W, act
+    ("conv3", 2, 16, 32, 10, 12, "PReLU"),       # Cout < 128: the generic 1-tap variant
+    ("conv3", 3, 64, 128, 21, 19, "PReLU"),      # odd output sizes: partial tiles masked
+    ("convT3", 2, 32, 256, 11, 11, "PReLU"),     # transposed layer (flipped taps, zero border), 256-row GEMM tile
+    ("conv3", 2, 256, 256, 30, 30, "none"),
+    ("convT3", 1, 512, 256, 28, 26, "ELU"),
+    ("conv3", 5, 512, 512, 13, 13, "Hardswish"),
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES, ids=lambda c: "-".join(str(v) for v in c))
+@pytest.mark.parametrize("tile", [2, 4])
+def test_layer_winograd(dev, case, tile):
+    """Winograd F(t x t, 3 x 3) form of a 3x3 layer (csrc/winograd.hip: input transform, 16 / 36 batched GEMMs in one launch,
+    output transform) against torch and against the direct kernel."""
+    kind, B, cin, cout, H, W, act = case
+    x = rnd((B, cin, H, W), 1)
+    bound = 1.0 / np.sqrt(cin * 9)
+    wshape = (cout, cin, 3, 3) if kind == "conv3" else (cin, cout, 3, 3)
+    w = rnd(wshape, 2, bound * 1.7)
+    b = rnd((cout,), 3, 0.2)
+    lib = _lib.load()
+    k = _lib.KIND[kind]
+    nbytes = lib.nd_winograd_packed_bytes(tile, cin, cout)
+    packed = torch.empty(nbytes // 4, dtype=torch.float32)
+    wc, bc = w.contiguous(), b.contiguous()
+    _lib.check(lib.nd_winograd_pack(tile, k, cin, cout, wc.data_ptr(), bc.data_ptr(), packed.data_ptr(), nbytes))
+    packed = packed.to(dev)
+    oh, ow = (H - 2, W - 2) if kind == "conv3" else (H + 2, W + 2)
+    y = torch.full((B, cout, oh, ow), float("nan"), dtype=torch.float32, device=dev)
+    wsb = lib.nd_layer_winograd_workspace_bytes(tile, k, B, cin, cout, H, W)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    xd = x.to(dev).contiguous()
+    _lib.check(lib.nd_layer_forward_winograd(tile, k, _lib.ACT[act], 0.13, packed.data_ptr(), xd.data_ptr(), B, cin, H, W, cout,
+                                             y.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr(dev)))
+    torch.cuda.synchronize()
+    ref = ref_layer(kind, x, w, b, act, 0.13)
+    err = assert_close(y, ref, f"winograd F({tile},3) {case}")
+    direct = layer_forward(dev, kind, x, w, b, act, 0.13)
+    scale = max(1.0, ref.abs().max().item())
+    assert (y - direct).abs().max().item() <= (2e-5 if tile == 2 else 1e-4) * scale
+    print(f"winograd F({tile},3) {case}: max abs err {err:.2e}")
+
+
 def test_layer_asymmetric_identity(dev):
     # exact-integer check of the fragment maps: an asymmetric integer kernel and integer inputs give integer
     # results that must match bit for bit (a transposed tap or swapped channel pairing cannot hide)
