@@ -219,6 +219,9 @@ int nd_layer_forward_winograd(int tile, int kind, int act, float slope, const vo
 int nd_conv_bench(int kind, int dtype, int batch, int cin, int cout, int h, int w, int variant, int iters,
                   void *workspace, size_t workspace_bytes, void *stream, float *mean_ms);
 
+int nd_winograd_bench(int tile, int kind, int batch, int cin, int cout, int h, int w, int iters, void *workspace,
+                      size_t workspace_bytes, void *stream, float *mean_ms);
+
 /* Name and average duration bookkeeping for bench.py: number of conv-kernel variants compiled in. */
 int nd_num_conv_variants(void);
 const char *nd_conv_variant_name(int variant);

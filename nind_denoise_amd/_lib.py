@@ -83,6 +83,7 @@ _SIGNATURES = {
                                   c_void_p]),
     "nd_mse": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t, c_void_p]),
     "nd_conv_bench": (c_int, [c_int] * 9 + [c_void_p, c_size_t, c_void_p, POINTER(c_float)]),
+    "nd_winograd_bench": (c_int, [c_int] * 8 + [c_void_p, c_size_t, c_void_p, POINTER(c_float)]),
     "nd_num_conv_variants": (c_int, []),
     "nd_conv_variant_name": (c_char_p, [c_int]),
     "nd_conv_split_enable": (c_int, [c_int]),

@@ -441,3 +441,54 @@ extern "C" int nd_conv_bench(int kind, int dtype, int batch, int cin, int cout, 
 
 extern "C" int nd_num_conv_variants(void) { return nd_conv_variant_count(); }
 extern "C" const char *nd_conv_variant_name(int v) { return nd_conv_variant_label(v); }
+
+// Same measurement for the Winograd form (tile = 2 | 4) of a 3x3 layer: the three passes per iteration.
+// workspace: nd_layer_winograd_workspace_bytes + nd_winograd_packed_bytes + 256 B
+extern "C" int nd_winograd_bench(int tile, int kind, int batch, int cin, int cout, int h, int w, int iters, void *ws,
+                                 size_t ws_bytes, void *stream, float *mean_ms) {
+    const size_t need = nd_layer_winograd_workspace_bytes(tile, kind, batch, cin, cout, h, w);
+    if (!need) ND_FAIL(ND_EINVAL, "nd_winograd_bench: bad shape / kind / tile");
+    const size_t wfloats = nd_wino_packed_floats(tile, cin, cout);
+    const size_t total = ((need + 255) & ~(size_t)255) + wfloats * 4;
+    if (!ws || ws_bytes < total) ND_FAIL(ND_ENOMEM, "nd_winograd_bench: workspace %zu B given, %zu B needed", ws_bytes, total);
+    hipStream_t s = (hipStream_t)stream;
+    LayerPlan pl = layer_plan(kind, batch, cin, cout, h, w, (char *)ws, ND_F32);
+    float *wpk = (float *)((char *)ws + ((need + 255) & ~(size_t)255));
+    hipLaunchKernelGGL(k_fill_random, dim3(2048), dim3(256), 0, s, (float *)ws, pl.bytes / 4, 12345u);
+    hipLaunchKernelGGL(k_fill_random, dim3(1024), dim3(256), 0, s, wpk, wfloats, 777u);
+    ConvDesc d;
+    d.kind = kind;
+    d.act = ND_ACT_PRELU;
+    d.slope = 0.2f;
+    d.slope_dev = nullptr;
+    d.cin = cin;
+    d.cout = cout;
+    d.wpk = wpk;
+    d.bias = nullptr;
+    d.in = pl.in;
+    d.out = pl.out;
+    d.out_plane0 = 0;
+    d.variant = -1;
+    d.part = pl.split;
+    d.part_bytes = kSplitScratchBytes;
+    void *scratch = (char *)ws + pl.bytes;
+    const size_t scratch_bytes = need - pl.bytes;
+    ND_TRY(nd_launch_conv_wino(tile, d, scratch, scratch_bytes, s));
+    hipEvent_t e0, e1;
+    ND_HIP(hipEventCreate(&e0));
+    ND_HIP(hipEventCreate(&e1));
+    ND_HIP(hipEventRecord(e0, s));
+    int rc = ND_OK;
+    for (int i = 0; i < iters && rc == ND_OK; ++i) rc = nd_launch_conv_wino(tile, d, scratch, scratch_bytes, s);
+    (void)hipEventRecord(e1, s);
+    if (hipStreamSynchronize(s) != hipSuccess && rc == ND_OK) {
+        nd_set_error("nd_winograd_bench: stream failed");
+        rc = ND_EHIP;
+    }
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (mean_ms) *mean_ms = ms / (iters > 0 ? iters : 1);
+    return rc;
+}

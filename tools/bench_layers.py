@@ -51,11 +51,12 @@ def main():
     ap.add_argument("--variants", default="auto")
     ap.add_argument("--layers", default="")
     ap.add_argument("--dtype", default="f32")
+    ap.add_argument("--winograd", action="store_true", help="also time the Winograd F(2,3) / F(4,3) form of every eligible 3x3 layer")
     args = ap.parse_args()
     lib = _lib.load()
     dev = torch.device("cuda:0")
     names = [lib.nd_conv_variant_name(v).decode() for v in range(lib.nd_num_conv_variants())]
-    ws = torch.empty(int(6e9), dtype=torch.uint8, device=dev)
+    ws = torch.empty(int(40e9 if args.winograd else 6e9), dtype=torch.uint8, device=dev)
     want = [s for s in args.layers.split(",") if s]
     tot = {}
     for (name, kind, cin, cout, h) in utnet_shapes(args.cs):
@@ -83,6 +84,17 @@ def main():
             print(f"{name:10s} {kind:8s} {cin:4d}->{cout:4d} {h:3d}^2  v{v:<2d} {names[v] if v >= 0 else 'auto':34s} {ms.value:8.4f} ms {tf:7.2f} TF", flush=True)
             tot.setdefault(v, 0.0)
             tot[v] += ms.value
+            if v == -1 and args.winograd and kind in ("conv3", "convT3") and cin % 16 == 0 and args.dtype == "f32":
+                for tile in (2, 4):
+                    rc = lib.nd_winograd_bench(tile, k, args.batch, cin, cout, h, h, args.iters, ws.data_ptr(), ws.numel(),
+                                               _lib.stream_ptr(dev), ms)
+                    if rc != 0:
+                        print(f"{name:10s} F({tile},3) skipped: {lib.nd_last_error().decode()}")
+                        continue
+                    tf = flops(kind, cin, cout, h, args.batch) / (ms.value * 1e-3) / 1e12
+                    print(f"{name:10s} {kind:8s} {cin:4d}->{cout:4d} {h:3d}^2  winograd F({tile},3){'':20s} {ms.value:8.4f} ms {tf:7.2f} TF (algorithmic)", flush=True)
+                    tot.setdefault(f"F{tile}", 0.0)
+                    tot[f"F{tile}"] += ms.value
     print("sum ms per variant:", {k: round(v, 3) for k, v in tot.items()})
 
 
