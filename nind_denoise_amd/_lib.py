@@ -87,6 +87,7 @@ _SIGNATURES = {
     "nd_num_conv_variants": (c_int, []),
     "nd_conv_variant_name": (c_char_p, [c_int]),
     "nd_conv_split_enable": (c_int, [c_int]),
+    "nd_conv_winograd_enable": (c_int, [c_int]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

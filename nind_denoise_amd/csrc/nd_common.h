@@ -80,6 +80,7 @@ size_t nd_wino_packed_floats(int T, int cin, int cout);
 int nd_wino_pack(int T, int kind, int cin, int cout, const float *w, const float *bias, float *packed);
 size_t nd_wino_scratch_bytes(int T, const QpBuf &in, int cin, int cout);
 int nd_launch_conv_wino(int T, const ConvDesc &d, void *scratch, size_t scratch_bytes, hipStream_t s);
+int nd_conv_winograd_enabled();
 const char *nd_conv_variant_label(int v);
 
 // packed size helpers (host)

@@ -70,12 +70,23 @@ int tensor_index(const std::string &name) {
 inline int lcin(const LayerSpec &l, int f) { return l.cin_mul ? l.cin_mul * f : 3; }
 inline int lcout(const LayerSpec &l, int f) { return l.cout_mul ? l.cout_mul * f : 3; }
 
+// Layers that run in Winograd F(4x4, 3x3) form on the fp32 inference path (winograd.hip): measured on the UtNet(64) shapes at
+// 256 tiles per launch it wins from 128 -> 128 channels up (1.26x there, 2.2 - 2.6x on the 512 / 1024-channel layers) and ties or
+// loses below (64 -> 128: 0.93x, 128 -> 64: 0.99x, 64 -> 64: 0.8x), where its transform passes cost more HBM time than the MFMAs saved
+constexpr int kWinoTile = 4;
+constexpr int kWinoChunk = 64;   // images per Winograd pass (bounds the V / M scratch; the rate is flat from 32 images up)
+inline bool wino_layer(const LayerSpec &l, int f, int dt) {
+    return dt == ND_F32 && (l.kind == ND_CONV3 || l.kind == ND_CONVT3) && l.cin_mul * f >= 128 && l.cout_mul * f >= 128 &&
+           (l.cin_mul * f) % 16 == 0;
+}
+
 // float offsets of every layer inside the packed blob
 struct BlobLayout {
     size_t off[kNumLayers];
+    size_t woff[kNumLayers];   // Winograd form of the layer (0: none)
     size_t total;
 };
-BlobLayout blob_layout(int f, int dt) {
+BlobLayout blob_layout(int f, int dt, bool with_wino = true) {
     BlobLayout b;
     size_t o = kHeaderFloats;
     for (int i = 0; i < kNumLayers; ++i) {
@@ -85,6 +96,13 @@ BlobLayout blob_layout(int f, int dt) {
             o += ((size_t)3 * lcin(l, f) + 3 + 3) / 4 * 4;  // raw [3][cin] + bias[3] for the VALU 1x1 kernel
         else
             o += nd_packed_floats(l.kind, lcin(l, f), lcout(l, f), dt);
+    }
+    for (int i = 0; i < kNumLayers; ++i) {
+        b.woff[i] = 0;
+        if (with_wino && wino_layer(kLayers[i], f, dt)) {
+            b.woff[i] = o;
+            o += (nd_wino_packed_floats(kWinoTile, lcin(kLayers[i], f), lcout(kLayers[i], f)) + 63) / 64 * 64;
+        }
     }
     b.total = o;
     return b;
@@ -112,9 +130,26 @@ int check_net(int funit, int h, int w, int batch, int dtype) {
 // ---------------------------------------------------------------- workspace plan
 enum Buf { X0, A1, CAT4, P1, A2, CAT3, P2, A3, CAT2, P3, A4, CAT1, P4, BT0, BT1, T1A, T1B, T2A, T2B, T3A, T3B, T4A, T4B, NBUF };
 
+struct Step {
+    int layer;  // index into kLayers, or -1 for a pool
+    Buf src, dst;
+    int dst_plane0_mul;  // destination plane offset = mul * funit / 4
+};
+// the conv stack between the input pack and the final 1x1 (UtNet.py:99-107)
+constexpr int kNumSteps = 26;
+const Step kSteps[kNumSteps] = {
+    {0, X0, A1, 0},     {1, A1, CAT4, 1},   {-1, CAT4, P1, 1},  {2, P1, A2, 0},    {3, A2, CAT3, 2},  {-1, CAT3, P2, 2},
+    {4, P2, A3, 0},     {5, A3, CAT2, 4},   {-1, CAT2, P3, 4},  {6, P3, A4, 0},    {7, A4, CAT1, 8},  {-1, CAT1, P4, 8},
+    {8, P4, BT0, 0},    {9, BT0, BT1, 0},   {10, BT1, CAT1, 0}, {11, CAT1, T1A, 0}, {12, T1A, T1B, 0}, {13, T1B, CAT2, 0},
+    {14, CAT2, T2A, 0}, {15, T2A, T2B, 0},  {16, T2B, CAT3, 0}, {17, CAT3, T3A, 0}, {18, T3A, T3B, 0}, {19, T3B, CAT4, 0},
+    {20, CAT4, T4A, 0}, {21, T4A, T4B, 0},
+};
+
 struct Plan {
     QpBuf buf[NBUF];
     float *split;   // split-K scratch shared by every conv launch of the stream (kSplitScratchBytes)
+    char *wino;     // Winograd V / M scratch (largest layer at kWinoChunk images)
+    size_t wino_bytes;
     size_t bytes;
 };
 
@@ -172,24 +207,19 @@ Plan make_plan(int f, int ch_, int cw_, int cap, int nimg, char *base, int dt) {
     add(T4B, f, l1 + 4, 0);
     p.split = (float *)(base + off);
     off += kSplitScratchBytes;
+    p.wino = base + off;
+    p.wino_bytes = 0;
+    for (const Step &st : kSteps) {
+        if (st.layer < 0 || !wino_layer(kLayers[st.layer], f, dt)) continue;
+        QpBuf v = p.buf[st.src];
+        v.B = cap < kWinoChunk ? cap : kWinoChunk;
+        const size_t need = nd_wino_scratch_bytes(kWinoTile, v, lcin(kLayers[st.layer], f), lcout(kLayers[st.layer], f));
+        if (need > p.wino_bytes) p.wino_bytes = need;
+    }
+    off += (p.wino_bytes + 255) & ~(size_t)255;
     p.bytes = off;
     return p;
 }
-
-struct Step {
-    int layer;  // index into kLayers, or -1 for a pool
-    Buf src, dst;
-    int dst_plane0_mul;  // destination plane offset = mul * funit / 4
-};
-// the conv stack between the input pack and the final 1x1 (UtNet.py:99-107)
-constexpr int kNumSteps = 26;
-const Step kSteps[kNumSteps] = {
-    {0, X0, A1, 0},     {1, A1, CAT4, 1},   {-1, CAT4, P1, 1},  {2, P1, A2, 0},    {3, A2, CAT3, 2},  {-1, CAT3, P2, 2},
-    {4, P2, A3, 0},     {5, A3, CAT2, 4},   {-1, CAT2, P3, 4},  {6, P3, A4, 0},    {7, A4, CAT1, 8},  {-1, CAT1, P4, 8},
-    {8, P4, BT0, 0},    {9, BT0, BT1, 0},   {10, BT1, CAT1, 0}, {11, CAT1, T1A, 0}, {12, T1A, T1B, 0}, {13, T1B, CAT2, 0},
-    {14, CAT2, T2A, 0}, {15, T2A, T2B, 0},  {16, T2B, CAT3, 0}, {17, CAT3, T3A, 0}, {18, T3A, T3B, 0}, {19, T3B, CAT4, 0},
-    {20, CAT4, T4A, 0}, {21, T4A, T4B, 0},
-};
 
 // ev (optional): kNumSteps+1 events, ev[i] recorded before step i, ev[kNumSteps] after the last one
 // pre (optional, training): kNumSlopes compact buffers that receive acc + bias of every activated layer
@@ -226,6 +256,20 @@ int run_stack(int f, int act, int dt, const float *blob, const Plan &pl, hipStre
         d.variant = -1;
         d.part = pl.split;
         d.part_bytes = kSplitScratchBytes;
+        if (!pre && bl.woff[st.layer] && nd_conv_winograd_enabled()) {
+            // Winograd form, kWinoChunk images per pass (views of the same buffers)
+            d.wpk = blob + bl.woff[st.layer];
+            d.bias = nullptr;
+            const int nimg = d.in.B;
+            for (int b0 = 0; b0 < nimg; b0 += kWinoChunk) {
+                ConvDesc c = d;
+                c.in.B = c.out.B = nimg - b0 < kWinoChunk ? nimg - b0 : kWinoChunk;
+                c.in.base = d.in.base + (size_t)b0 * d.in.Hb * d.in.Wb * 4;
+                c.out.base = d.out.base + (size_t)b0 * d.out.Hb * d.out.Wb * 4;
+                ND_TRY(nd_launch_conv_wino(kWinoTile, c, pl.wino, pl.wino_bytes, s));
+            }
+            continue;
+        }
         ND_TRY(nd_launch_conv(d, s));
     }
     if (ev) ND_HIP(hipEventRecord(ev[si], s));

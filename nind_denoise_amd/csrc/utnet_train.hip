@@ -451,7 +451,7 @@ extern "C" int nd_utnet_param_range(int funit, int tensor_idx, size_t *offset, s
 }
 extern "C" size_t nd_utnet_train_blob_bytes(int funit) {
     if (funit < 8 || funit % 8) return 0;
-    return (blob_layout(funit, ND_F32).total + bwd_blob_layout(funit).total) * sizeof(float);
+    return (blob_layout(funit, ND_F32, false).total + bwd_blob_layout(funit).total) * sizeof(float);
 }
 extern "C" size_t nd_utnet_train_workspace_bytes(int funit, int cs, int batch) {
     if (check_train(funit, cs, batch) != ND_OK) return 0;
@@ -483,7 +483,7 @@ extern "C" int nd_utnet_train_step(int funit, const float *params, float *grads,
     hipStream_t s = (hipStream_t)stream;
     const int f = funit, B = batch;
     const ParamLayout pl = param_layout(f);
-    const BlobLayout bl = blob_layout(f, ND_F32);
+    const BlobLayout bl = blob_layout(f, ND_F32, false);   // training keeps the direct form (pre-activation copies)
     const BwdBlob bb = bwd_blob_layout(f);
     float *fblob = (float *)blobs;
     float *bblob = fblob + bl.total;

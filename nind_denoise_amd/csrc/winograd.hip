@@ -174,6 +174,15 @@ WinoGeo wino_geo(int T, const QpBuf &in, int cin, int cout) {
 }
 }  // namespace
 
+// ------------------------------------------------------------------ switch
+static int g_wino_on = 1;
+int nd_conv_winograd_enabled() { return g_wino_on; }
+extern "C" int nd_conv_winograd_enable(int on) {
+    const int was = g_wino_on;
+    g_wino_on = on ? 1 : 0;
+    return was;
+}
+
 // ------------------------------------------------------------------ packing (host)
 // layout: P x [1-tap packed GEMM weights U_pos (pack.hip layout, zero bias)] + bias[cout rounded up to 4]
 size_t nd_wino_packed_floats(int T, int cin, int cout) {
