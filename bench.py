@@ -68,8 +68,17 @@ def parse():
                          "BASELINE configs 3 / 4 (16-bit storage, fp32 accumulate)")
     ap.add_argument("--cpu-sample-tiles", type=int, default=0, help="0: sized for ~15 s of CPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-winograd", action="store_true", help="direct convolution on every layer (A/B switch)")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
+
+
+def lib_winograd_on():
+    from nind_denoise_amd import _lib
+    lib = _lib.load()
+    was = lib.nd_conv_winograd_enable(1)
+    lib.nd_conv_winograd_enable(was)
+    return bool(was)
 
 
 def conv_stack_profile(net, cs, batch, dev, reps=3):
@@ -93,6 +102,33 @@ def conv_stack_profile(net, cs, batch, dev, reps=3):
     steps = [dict(name=lib.nd_utnet_step_name(i).decode(), ms=float(med[i]), flop=float(fl[i]), conv=bool(isc[i]))
              for i in range(n)]
     return steps
+
+
+def executed_flop(name, flop, cs, batch, funit, dtype):
+    """MFMA-executed FLOP of one conv-stack step: the algorithmic FLOP for the direct layers, 36 GEMMs of Cout x Cin x tiles for
+    the layers that run in Winograd F(4x4, 3x3) form (csrc/utnet_net.h: wino_layer -- fp32, 3x3, Cin and Cout >= 128)."""
+    import math
+    f, h = funit, cs + 4
+    shapes = {}
+    for n, (ci, co) in enumerate([(3, f), (f, 2 * f), (2 * f, 4 * f), (4 * f, 8 * f)], start=1):
+        shapes[f"convs{n}.0"] = (ci, co, h - 2)
+        shapes[f"convs{n}.2"] = (co, co, h - 4)
+        h = (h - 4) // 2
+    shapes["bottom.0"] = (8 * f, 16 * f, h - 2)
+    shapes["bottom.2"] = (16 * f, 16 * f, h)
+    c = 16 * f
+    for n in range(1, 5):
+        h *= 2
+        shapes[f"tconvs{n}.0"] = (c, c // 2, h + 2)
+        shapes[f"tconvs{n}.2"] = (c // 2, c // 2, h + 4)
+        h += 4
+        c //= 2
+    if name not in shapes or dtype != "f32":
+        return flop
+    ci, co, hout = shapes[name]
+    if ci < 128 or co < 128:
+        return flop
+    return 36 * 2.0 * ci * co * math.ceil(hout / 4) ** 2 * batch
 
 
 def pmc_traffic(cs, batch, funit):
@@ -165,6 +201,8 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     _lib.load()
+    if args.no_winograd:
+        _lib.load().nd_conv_winograd_enable(0)
 
     W, H, cs, ucs, ol = args.width, args.height, args.cs, args.ucs, args.ol
     sd = synth.make_utnet_state_dict(funit=args.funit, seed=123)
@@ -253,13 +291,21 @@ def main():
             conv_ms = sum(s["ms"] for s in steps if s["conv"])
             conv_flop = sum(s["flop"] for s in steps if s["conv"])
             achieved = conv_flop / (conv_ms * 1e-3) / 1e12
+            wino = args.dtype == "f32" and lib_winograd_on()
+            exe_flop = sum(executed_flop(s["name"], s["flop"], cs, b, args.funit, args.dtype if wino else "") for s in steps if s["conv"])
             out["roofline"] = {
                 "bound": "mfma",
-                "kernel": f"conv_qp<{args.dtype}> (22 launches per tile batch: every 3x3 / transposed conv of UtNet)",
+                "kernel": f"conv_qp<{args.dtype}>: the 22 weighted layers of the UtNet conv stack per tile batch"
+                          + (" -- direct 3x3 implicit GEMM (5 layers), 36 batched 1-tap GEMMs per Winograd F(4x4,3x3) layer (13 layers, "
+                             "layer time includes the two transform passes), 2x2-s2 transposed (4 layers)" if wino else ""),
                 "achieved": round(achieved, 3),
                 "peak": PEAK_MFMA_TFLOPS[args.dtype],
                 "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_MFMA_TFLOPS[args.dtype], 4),
+                "note": "achieved = ALGORITHMIC FLOP (direct-convolution count, SURVEY.md 8d) / time; with Winograd layers the matrix "
+                        "cores execute fewer FLOP than that, so the fraction can exceed 1 -- mfma_executed_* is what the MFMA pipe ran",
+                "mfma_executed_tflops": round(exe_flop / (conv_ms * 1e-3) / 1e12, 3),
+                "mfma_executed_frac": round(exe_flop / (conv_ms * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS[args.dtype], 4),
                 "traffic": (pmc_traffic(cs, b, args.funit) or {}).get("bytes_per_launch") if args.dtype == "f32" else None,
                 "traffic_unit": "HBM bytes per launch of the 3x3 conv_qp variant (PMC FETCH_SIZE*2 + WRITE_SIZE)",
                 "traffic_detail": pmc_traffic(cs, b, args.funit) if args.dtype == "f32" else None,

@@ -7,6 +7,9 @@
 //   3. k_wino_output  M[pos][Cout/4][tile] -> A^T m A + bias, activation -> destination buffer (HBM-bound)
 // It pays where channels are wide: pass 1 + 3 move ~2 (T+2)^2/T^2 x (|X| + |Y|) bytes, pass 2 saves 9 T^2/(T+2)^2 of the MFMAs.
 // ConvTranspose2d(3) is the same valid correlation on its zero-bordered input with flipped / transposed weights (as in pack.hip).
+#include <algorithm>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "nd_common.h"
@@ -195,7 +198,18 @@ int nd_wino_pack(int T, int kind, int cin, int cout, const float *w, const float
     if (kind != ND_CONV3 && kind != ND_CONVT3) ND_FAIL(ND_EINVAL, "winograd: 3x3 layers only");
     const int A = T + 2, P = A * A;
     std::vector<float> u((size_t)P * cout * cin);
-    for (int co = 0; co < cout; ++co)
+    // host threads: the transform + repack of UtNet(64)'s 13 Winograd layers is ~2 s on one core (model load time)
+    auto parallel_for = [](int n, auto &&fn) {
+        const int nt = std::max(1, std::min(n, std::min(16, (int)std::thread::hardware_concurrency())));
+        std::atomic<int> next(0);
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t)
+            th.emplace_back([&] {
+                for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i);
+            });
+        for (auto &x : th) x.join();
+    };
+    parallel_for(cout, [&](int co) {
         for (int ci = 0; ci < cin; ++ci) {
             double g[3][3], tmp[6][3], U[6][6];
             for (int ky = 0; ky < 3; ++ky)
@@ -215,8 +229,9 @@ int nd_wino_pack(int T, int kind, int cin, int cout, const float *w, const float
             for (int i = 0; i < A; ++i)
                 for (int j = 0; j < A; ++j) u[((size_t)(i * A + j) * cout + co) * cin + ci] = (float)U[i][j];
         }
+    });
     const size_t gf = gemm_floats(cin, cout);
-    for (int p = 0; p < P; ++p) nd_pack_layer(ND_CONV1, cin, cout, ND_F32, u.data() + (size_t)p * cout * cin, nullptr, packed + p * gf);
+    parallel_for(P, [&](int p) { nd_pack_layer(ND_CONV1, cin, cout, ND_F32, u.data() + (size_t)p * cout * cin, nullptr, packed + p * gf); });
     float *b = packed + (size_t)P * gf;
     for (int co = 0; co < (cout + 3) / 4 * 4; ++co) b[co] = (bias && co < cout) ? bias[co] : 0.f;
     return ND_OK;

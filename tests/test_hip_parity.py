@@ -404,6 +404,17 @@ def test_utnet_f64_cs264_golden(dev, golden_dir):
         assert_close(yb[:1], torch.from_numpy(d["y"]), "utnet f64 cs264, split-K off")
     finally:
         lib.nd_conv_split_enable(was)
+    # the default path runs the >= 128-channel 3x3 layers in Winograd F(4x4,3x3) form (nd_conv_winograd_enable); the direct
+    # form of every layer must meet the same bar, and the two agree far inside it
+    y_w = net(x)
+    was = lib.nd_conv_winograd_enable(0)
+    try:
+        y_d = net(x)
+        err_d = assert_close(y_d, torch.from_numpy(d["y"]), "utnet f64 cs264, direct convolution everywhere")
+    finally:
+        lib.nd_conv_winograd_enable(was)
+    assert was == 1 and (y_w - y_d).abs().max().item() < 1e-5
+    print(f"utnet f64 cs264 direct-only max abs err {err_d:.3e}, winograd vs direct {(y_w - y_d).abs().max().item():.3e}")
     print(f"utnet f64 cs264 max abs err {err:.3e}")
 
 
