@@ -74,7 +74,7 @@ static const size_t kSplitScratchBytes = (size_t)512 * 64 * 1024 * 4;
 int nd_launch_conv(const ConvDesc &d, hipStream_t stream);
 static inline int nd_launch_conv_f32(const ConvDesc &d, hipStream_t stream) { return nd_launch_conv(d, stream); }
 int nd_conv_variant_count();
-int nd_conv_variant_gemm(int rows);   // 1-tap fp32 variant with a 256- or 128-row workgroup tile (Winograd GEMMs)
+int nd_conv_variant_gemm(int cin, int cout);   // 1-tap fp32 variant (256- / 128-row workgroup tiles) for a Winograd GEMM
 // Winograd F(T x T, 3 x 3), T = 2 | 4 (winograd.hip): fp32 inference path of the wide 3x3 layers
 size_t nd_wino_packed_floats(int T, int cin, int cout);
 int nd_wino_pack(int T, int kind, int cin, int cout, const float *w, const float *bias, float *packed);

@@ -289,7 +289,7 @@ int nd_launch_conv_wino(int T, const ConvDesc &d, void *scratch, size_t scratch_
     e.out.planes = out_planes;
     e.out.pstride = g.mnp;
     e.out_plane0 = 0;
-    e.variant = d.cout % 256 == 0 ? nd_conv_variant_gemm(256) : (d.cout % 128 == 0 ? nd_conv_variant_gemm(128) : -1);
+    e.variant = nd_conv_variant_gemm(d.cin, d.cout);
     e.part = d.part;
     e.part_bytes = d.part_bytes;
     e.nbatch = P;
