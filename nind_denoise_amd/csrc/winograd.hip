@@ -102,51 +102,68 @@ __global__ __launch_bounds__(256) void k_wino_input(const f32x4 *__restrict__ x,
     }
 }
 
-// out = act(A^T m A + bias).  grid (ceil(tiles / 256), Cout / 4)
+// out = act(A^T m A + bias).  grid (ceil(tiles / 128), Cout / 4), 128 threads.
+// A thread owns one tile (T x T pixels), but stores go out PIXEL-contiguous across the lanes: the workgroup's 128 tiles are
+// consecutive in x, so row r of all of them is staged in LDS and written as whole 1 KiB wave stores instead of 16-byte
+// pieces at a 64-byte stride (partial cache lines that the L2 has to merge: measured 3.3 TB/s before)
 template <int T>
-__global__ __launch_bounds__(256) void k_wino_output(const f32x4 *__restrict__ m, long mnp, long mbs, int B, int TY, int TX, int Hv,
+__global__ __launch_bounds__(128) void k_wino_output(const f32x4 *__restrict__ m, long mnp, long mbs, int B, int TY, int TX, int Hv,
                                                      int Wv, const float *__restrict__ bias, int act, float slope_imm,
                                                      const float *__restrict__ slope_dev, f32x4 *__restrict__ out, long onp,
                                                      int out_plane0, int Ho, int Wo, int opad) {
     constexpr int A = Wino<T>::A;
-    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    constexpr int NT = 128;
+    __shared__ f32x4 sm[T][NT * T];
+    const long t0 = (long)blockIdx.x * NT;
+    const long t = t0 + threadIdx.x;
     const long tiles = (long)B * TY * TX;
-    if (t >= tiles) return;
     const int q = blockIdx.y;
-    const int tx = (int)(t % TX), ty = (int)((t / TX) % TY), b = (int)(t / ((long)TX * TY));
-    const f32x4 *src = m + (long)q * mnp + t;
-    f32x4 r[A][T];
-#pragma unroll
-    for (int i = 0; i < A; ++i) {
-        f32x4 row[A];
-#pragma unroll
-        for (int j = 0; j < A; ++j) row[j] = src[(long)(i * A + j) * mbs];
-        Wino<T>::at(row, r[i]);   // m A  (row-wise A^T)
-    }
     const f32x4 bv = *(const f32x4 *)(bias + 4 * q);
     const float slope = act == ND_ACT_NONE ? 1.f : (slope_dev ? *slope_dev : slope_imm);
-    f32x4 *dst = out + (long)(out_plane0 + q) * onp + ((long)b * Ho + T * ty + opad) * Wo + T * tx + opad;
+    if (t < tiles) {
+        const f32x4 *src = m + (long)q * mnp + t;
+        f32x4 r[A][T];
 #pragma unroll
-    for (int j = 0; j < T; ++j) {
-        f32x4 c[A], o[T];
+        for (int i = 0; i < A; ++i) {
+            f32x4 row[A];
 #pragma unroll
-        for (int i = 0; i < A; ++i) c[i] = r[i][j];
-        Wino<T>::at(c, o);
-#pragma unroll
-        for (int i = 0; i < T; ++i) {
-            if (T * ty + i >= Hv || T * tx + j >= Wv) continue;
-            f32x4 y = o[i] + bv;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float u = y[e];
-                switch (act) {
-                    case ND_ACT_ELU: y[e] = u > 0.f ? u : expm1f(u); break;
-                    case ND_ACT_HARDSWISH: y[e] = u * fminf(fmaxf(u + 3.f, 0.f), 6.f) / 6.f; break;
-                    default: y[e] = u > 0.f ? u : u * slope; break;   // PReLU; "none" is slope 1
-                }
-            }
-            dst[(long)i * Wo + j] = y;
+            for (int j = 0; j < A; ++j) row[j] = src[(long)(i * A + j) * mbs];
+            Wino<T>::at(row, r[i]);   // m A  (row-wise A^T)
         }
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            f32x4 c[A], o[T];
+#pragma unroll
+            for (int i = 0; i < A; ++i) c[i] = r[i][j];
+            Wino<T>::at(c, o);
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+                f32x4 y = o[i] + bv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float u = y[e];
+                    switch (act) {
+                        case ND_ACT_ELU: y[e] = u > 0.f ? u : expm1f(u); break;
+                        case ND_ACT_HARDSWISH: y[e] = u * fminf(fmaxf(u + 3.f, 0.f), 6.f) / 6.f; break;
+                        default: y[e] = u > 0.f ? u : u * slope; break;   // PReLU; "none" is slope 1
+                    }
+                }
+                sm[i][threadIdx.x * T + j] = y;
+            }
+        }
+    }
+    __syncthreads();
+    f32x4 *dst = out + (long)(out_plane0 + q) * onp;
+    for (int p = threadIdx.x; p < NT * T; p += NT) {
+        const long tt = t0 + p / T;
+        if (tt >= tiles) break;
+        const int j = p % T;
+        const int tx = (int)(tt % TX), ty = (int)((tt / TX) % TY), b = (int)(tt / ((long)TX * TY));
+        const int x = T * tx + j;
+        if (x >= Wv) continue;
+#pragma unroll
+        for (int i = 0; i < T; ++i)
+            if (T * ty + i < Hv) dst[((long)b * Ho + T * ty + i + opad) * Wo + x + opad] = sm[i][p];
     }
 }
 
@@ -299,13 +316,13 @@ int nd_launch_conv_wino(int T, const ConvDesc &d, void *scratch, size_t scratch_
     ND_TRY(nd_launch_conv(e, s));
 
     const float *bias = d.wpk + (size_t)P * gemm_floats(d.cin, d.cout);
-    dim3 go((unsigned)((g.tiles + 255) / 256), out_planes);
+    dim3 go((unsigned)((g.tiles + 127) / 128), out_planes);
     f32x4 *out = (f32x4 *)d.out.base;
     if (T == 2)
-        hipLaunchKernelGGL(k_wino_output<2>, go, dim3(256), 0, s, (const f32x4 *)m, g.mnp, g.mbs, d.in.B, g.TY, g.TX, g.Hv, g.Wv, bias,
+        hipLaunchKernelGGL(k_wino_output<2>, go, dim3(128), 0, s, (const f32x4 *)m, g.mnp, g.mbs, d.in.B, g.TY, g.TX, g.Hv, g.Wv, bias,
                            d.act, d.slope, d.slope_dev, out, d.out.np(), d.out_plane0, d.out.Hb, d.out.Wb, d.out.pad);
     else
-        hipLaunchKernelGGL(k_wino_output<4>, go, dim3(256), 0, s, (const f32x4 *)m, g.mnp, g.mbs, d.in.B, g.TY, g.TX, g.Hv, g.Wv, bias,
+        hipLaunchKernelGGL(k_wino_output<4>, go, dim3(128), 0, s, (const f32x4 *)m, g.mnp, g.mbs, d.in.B, g.TY, g.TX, g.Hv, g.Wv, bias,
                            d.act, d.slope, d.slope_dev, out, d.out.np(), d.out_plane0, d.out.Hb, d.out.Wb, d.out.pad);
     ND_HIP(hipGetLastError());
     return ND_OK;
