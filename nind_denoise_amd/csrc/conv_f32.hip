@@ -12,6 +12,7 @@ static const Variant g_f32_extra[] = {
     ND_VARIANT(ND_F32, "f32", 2, 2, 2, 4, 1, 2, false, 3),  // 1 tap, M128 x N256
     ND_VARIANT(ND_F32, "f32", 2, 4, 4, 2, 1, 4, false, 2),  // 1 tap, M256 x N256, 4 K blocks per step on 2 stages: 3-4 % faster from Cin = 512
     ND_VARIANT(ND_F32, "f32", 2, 4, 2, 4, 1, 4, false, 2),  // 1 tap, M128 x N512, 4 K blocks per step: 2-4 % over M128 x N256
+    ND_VARIANT(ND_F32, "f32", 2, 4, 4, 2, 1, 4, true, 2),   // up (2x2 s2), M256 x N256, 4 K blocks per step: 5-9 % over M128 x N256
 };
 constexpr int kExtra = (int)(sizeof(g_f32_extra) / sizeof(g_f32_extra[0]));
 static const int g_nvariants = 3 * kGroup + kExtra;
@@ -216,6 +217,7 @@ static int pick_variant(const ConvDesc &d, int M) {
     }
     if (taps == 4) return g0 + (variant_lds(variant_at(g0 + 12), d.in) <= kMaxLds ? 12 : 13);
     if (KB % 2) return g0 + (up ? 7 : 5);
+    if (up && dt == ND_F32 && M % 256 == 0 && KB % 4 == 0) return 3 * kGroup + 6;
     if (up) return g0 + (M >= 128 ? (KB % 4 == 0 ? 10 : 8) : (KB % 4 == 0 ? 9 : 6));
     return g0 + 4;
 }
