@@ -177,6 +177,18 @@ extern "C" int nd_conv_split_enable(int on) {
     return was;
 }
 
+void nd_plan_split(long ntiles, int nchunks, long slots, long max_items, int *first, int *S, int *cps) {
+    const SplitPlan sp = plan_split(ntiles, nchunks, slots, g_split_on ? max_items : 0, kSplitOver);
+    *first = sp.first;
+    *S = sp.S;
+    *cps = sp.cps;
+}
+int nd_launch_split_finish(const ConvParams &p, int n_split_tiles, int mblk, int nblk, int up, int dt, hipStream_t s) {
+    hipLaunchKernelGGL(k_split_finish, dim3((unsigned)n_split_tiles, mblk / 4), dim3(256), 0, s, p, mblk, nblk, up, dt);
+    ND_HIP(hipGetLastError());
+    return ND_OK;
+}
+
 static int pick_variant(const ConvDesc &d, int M) {
     const int taps = nd_taps(d.kind);
     const bool up = d.kind == ND_CONVT2S2;

@@ -1,0 +1,400 @@
+// 3x3 convolution with a 1-D Winograd F(2,3) along x inside the implicit-GEMM kernel (fp32 inference, narrow full-resolution layers).
+//
+// The 64-channel layers of UtNet are HBM-bound in any multi-pass Winograd form (winograd.hip) and MFMA-bound in the direct
+// form (conv_qp.inc).  This kernel keeps the direct kernel's structure -- persistent workgroups, LDS-DMA halo images of the RAW
+// input, split-K tail -- and shortens only the matrix work:  for an output pixel PAIR (x0, x0+1) and kernel row ky
+//     d0..d3 = X[y+ky][x0 .. x0+3]          v = (d0-d2, d1+d2, d2-d1, d1-d3)                  (in registers, 4 VALU ops per float4)
+//     m_xi  += U[ky][xi] (Cout x Cin) * v_xi,   U[ky] = (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2) of that kernel row      (MFMA)
+//     Y[x0] = m0+m1+m2,  Y[x0+1] = m1-m2-m3                                                   (in registers, epilogue)
+// 12 weight planes and 4 accumulator sets per pair instead of 9 taps x 2 pixels: 2/3 of the MFMAs, the same LDS-DMA bytes.
+// An N tile enumerates valid pixel PAIRS (rows have an even number of valid pixels: 16k+56 tile sizes guarantee it at the levels
+// this is used for; the launcher refuses odd rows).  Result differs from the direct kernel by fp32 re-association (~1e-6).
+#include "conv_qp.inc"
+
+namespace {
+
+// MR : 32-row tiles per wave (x 4 position sets);  one 32-pair group per wave;  WM x WN waves
+template <int MR, int WM, int WN, int NSTAGE>
+__global__ __launch_bounds__(64 * WM * WN) void conv_w1d(ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NW = WM * WN;
+    constexpr int MTB = MR * WM;
+    constexpr int NBLK = 32 * WN;           // pixel pairs per workgroup tile
+    constexpr int TAPS = 12;                // weight planes per K block: 3 kernel rows x 4 positions
+    constexpr int WBYTES = MTB * TAPS * 1024;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int j = lane & 31, h = lane >> 5;
+    const int nwg = gridDim.x;
+    const int bid = blockIdx.x;
+    const int vb = (nwg % 8 == 0) ? (bid % 8) * (nwg / 8) + bid / 8 : bid;
+
+    const int G = p.G;
+    const int planeB = G * 1024;
+    const int stageB = WBYTES + 2 * planeB;
+
+    const int nchunks = p.KB;
+    const int nitems = p.nitems;
+    const int my_items = vb < nitems ? (nitems - vb + nwg - 1) / nwg : 0;
+    struct Item { int tile, c0, c1, slice; };
+    auto decode = [&](int w) -> Item {
+        Item it;
+        if (w < p.split_first) {
+            it.tile = w; it.c0 = 0; it.c1 = nchunks; it.slice = -1;
+        } else {
+            const int u = w - p.split_first;
+            const int t = u / p.S, ks = u - t * p.S;
+            it.tile = p.split_first + t;
+            it.c0 = ks * p.cps;
+            it.c1 = it.c0 + p.cps < nchunks ? it.c0 + p.cps : nchunks;
+            it.slice = u;
+        }
+        return it;
+    };
+    int nsteps = 0;
+    if (p.split_first >= nitems)
+        nsteps = my_items * nchunks;
+    else
+        for (int i = 0; i < my_items; ++i) {
+            const Item it = decode(vb + i * nwg);
+            nsteps += it.c1 - it.c0;
+        }
+    if (nsteps == 0) return;
+
+    // (image, compact PAIR index) of the l-th pair of N tile nb  (p.Wv = pairs per row, p.PV = pairs per image)
+    auto pair_of = [&](int nb, int l, int &img, int &r) -> bool {
+        bool ok;
+        if (p.tpi) {
+            img = nb / p.tpi;
+            r = (nb - img * p.tpi) * NBLK + l;
+            ok = r < p.PV;
+            r = ok ? r : p.PV - 1;
+        } else {
+            const long g = (long)nb * NBLK + l;
+            const long tot = (long)p.nimg * p.PV;
+            ok = g < tot;
+            const long gc = ok ? g : tot - 1;
+            img = (int)(gc / p.PV);
+            r = (int)(gc - (long)img * p.PV);
+        }
+        return ok;
+    };
+    auto q_of = [&](int img, int r) -> long {   // linear input index of the pair's first pixel
+        const int y = r / p.Wv;
+        return (long)img * p.P + (long)y * p.Wb + 2 * (r - y * p.Wv);
+    };
+    auto tile_q0 = [&](int nb) -> long {
+        int img, r;
+        pair_of(nb, 0, img, r);
+        return q_of(img, r);
+    };
+
+    // ---- DMA cursor (as in conv_qp)
+    int f_id = vb, f_c = 0, f_end = 0, f_stage = 0, issued = 0;
+    const float *f_w;
+    const f32x4 *f_a;
+    auto set_fill_tile = [&](int w) {
+        const Item it = decode(w);
+        f_c = it.c0;
+        f_end = it.c1;
+        const int nb = it.tile / p.n_tiles_m, mb = it.tile - nb * p.n_tiles_m;
+        f_w = p.wpk + (size_t)mb * MTB * p.KB * TAPS * 256 + lane * 4;
+        f_a = p.in + tile_q0(nb) + lane;
+    };
+    set_fill_tile(f_id);
+    constexpr int NFILL = NW > 4 ? 4 : NW;
+    auto fill_next = [&]() {
+        if (issued >= nsteps) return;
+        char *sb = smem + f_stage * stageB;
+        if (wave < NFILL) {
+#pragma unroll
+            for (int mt = 0; mt < MTB; ++mt) {
+                const float *src = f_w + ((size_t)mt * p.KB + (size_t)f_c) * TAPS * 256;
+                char *dst = sb + mt * TAPS * 1024;
+                for (int q = wave; q < TAPS; q += NFILL) glds16(src + q * 256, dst + q * 1024);
+            }
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                const f32x4 *src = f_a + (size_t)(f_c * 2 + pl) * p.in_plane;
+                char *dst = sb + WBYTES + pl * planeB;
+                for (int g = wave; g < G; g += NFILL) glds16(src + g * 64, dst + g * 1024);
+            }
+        }
+        ++issued;
+        f_stage = (f_stage + 1 == NSTAGE) ? 0 : f_stage + 1;
+        if (++f_c == f_end) {
+            f_id += nwg;
+            if (f_id < nitems) set_fill_tile(f_id);
+        }
+    };
+
+    const int aOff = (wm * MR) * TAPS * 1024 + lane * 16;
+    auto lane_offset = [&](int w) -> int {
+        const int nb = decode(w).tile / p.n_tiles_m;
+        int img, r;
+        pair_of(nb, wn * 32 + j, img, r);
+        return WBYTES + h * planeB + (int)(q_of(img, r) - tile_q0(nb)) * 16;
+    };
+    int bOff = lane_offset(vb);
+    const int rowB = p.Wb * 16;
+
+    f32x16 acc[4][MR];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][m][r] = 0.f;
+
+    const float slope = p.act == ND_ACT_NONE ? 1.f : (p.slope_dev ? *p.slope_dev : p.slope);
+
+    // combine the four position accumulators of (mr, g) into the two pixels' sums (clears them)
+    auto combine = [&](int mr, int g, f32x4 &y0, f32x4 &y1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float m0 = acc[0][mr][4 * g + e], m1 = acc[1][mr][4 * g + e], m2 = acc[2][mr][4 * g + e], m3 = acc[3][mr][4 * g + e];
+            y0[e] = m0 + m1 + m2;
+            y1[e] = m1 - m2 - m3;
+            acc[0][mr][4 * g + e] = acc[1][mr][4 * g + e] = acc[2][mr][4 * g + e] = acc[3][mr][4 * g + e] = 0.f;
+        }
+    };
+
+    auto epilogue = [&](int id) {
+        const int nb = id / p.n_tiles_m, mb = id - nb * p.n_tiles_m;
+        int bi, r;
+        const bool valid = pair_of(nb, wn * 32 + j, bi, r);
+        const int y = r / p.Wv, xp = r - y * p.Wv;
+        const long pix = (long)bi * p.Po + (long)(y + p.opad) * p.Wo + 2 * xp + p.opad;
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int m8 = ((mb * MTB + wm * MR + mr) * 32) + 8 * g;
+                const f32x8 b8 = sload8(p.bias + m8);
+                const int m4 = m8 + 4 * h;
+                f32x4 y0, y1;
+                combine(mr, g, y0, y1);
+                if (valid && m4 < p.M) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float bv = h ? b8[4 + e] : b8[e];
+                        y0[e] = apply_act(y0[e] + bv, p.act, slope);
+                        y1[e] = apply_act(y1[e] + bv, p.act, slope);
+                    }
+                    f32x4 *dst = p.out + (long)(p.out_plane0 + (m4 >> 2)) * p.out_plane + pix;
+                    dst[0] = y0;
+                    dst[1] = y1;
+                }
+            }
+    };
+    // a K slice of a split tile: combined raw sums, tile-local [quad][pixel] layout of k_split_finish (2 * NBLK pixels)
+    auto epilogue_partial = [&](int slice) {
+        f32x4 *dst = p.part + (size_t)slice * (MTB * 8) * (2 * NBLK);
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 y0, y1;
+                combine(mr, g, y0, y1);
+                f32x4 *d2 = dst + (size_t)((wm * MR + mr) * 8 + 2 * g + h) * (2 * NBLK) + 2 * (wn * 32 + j);
+                d2[0] = y0;
+                d2[1] = y1;
+            }
+    };
+
+    // ---- prologue
+#pragma unroll
+    for (int i = 0; i < NSTAGE - 1; ++i) fill_next();
+
+    int c_id = vb, c_stage = 0;
+    Item c_it = decode(vb);
+    int c_c = c_it.c0;
+    for (int s = 0; s < nsteps; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        fill_next();
+        const char *sb = smem + c_stage * stageB;
+        const char *bp = sb + bOff;
+        f32x4 d[2][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d[0][i] = *(const f32x4 *)(bp + i * 16);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            if (ky + 1 < 3) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d[(ky + 1) & 1][i] = *(const f32x4 *)(bp + (ky + 1) * rowB + i * 16);
+            }
+            const f32x4 *dd = d[ky & 1];
+            const f32x4 v[4] = {dd[0] - dd[2], dd[1] + dd[2], dd[2] - dd[1], dd[1] - dd[3]};
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi) {
+                f32x4 a[MR];
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr) a[mr] = *(const f32x4 *)(sb + aOff + (mr * TAPS + ky * 4 + xi) * 1024);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int mr = 0; mr < MR; ++mr)
+                        acc[xi][mr] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mr][q], v[xi][q], acc[xi][mr], 0, 0, 0);
+            }
+        }
+        c_stage = (c_stage + 1 == NSTAGE) ? 0 : c_stage + 1;
+        if (++c_c == c_it.c1) {
+            if (c_it.slice >= 0)
+                epilogue_partial(c_it.slice);
+            else
+                epilogue(c_it.tile);
+            c_id += nwg;
+            if (c_id < nitems) {
+                c_it = decode(c_id);
+                bOff = lane_offset(c_id);
+            }
+            c_c = c_it.c0;
+        }
+    }
+}
+
+constexpr int kW1dMR = 2, kW1dWM = 1, kW1dWN = 8, kW1dStages = 2;
+constexpr int kW1dMblk = 32 * kW1dMR * kW1dWM, kW1dPairs = 32 * kW1dWN;
+
+// input pixels spanned by one N tile (+ halo): n pairs = 2n valid pixels, row and image gaps, 2 rows + 4 pixels of halo
+int w1d_span(const QpBuf &in, bool cross) {
+    const int Hv = in.Hb - 2, Wp = (in.Wb - 2) / 2, n = kW1dPairs;
+    long span = 2L * n + (long)(in.Wb - 2 * Wp) * ((n - 1) / Wp + 1);
+    if (cross) span += (long)(in.Hb * in.Wb - Hv * in.Wb) * ((n - 1) / (Hv * Wp) + 1);
+    const long whole = (long)in.B * in.Hb * in.Wb;
+    if (cross && span > whole) span = whole;
+    return (int)(span + 2 * in.Wb + 4);
+}
+size_t w1d_lds(int G) { return (size_t)kW1dStages * ((size_t)(kW1dMblk / 32) * 12 * 1024 + (size_t)2 * G * 1024); }
+
+}  // namespace
+
+// packed layout: [32-row tile][K block][12 = ky*4 + xi][lane][4] + bias[mtiles*32]   (as pack.hip, 12 planes instead of 9 taps)
+size_t nd_w1d_packed_floats(int cin, int cout) {
+    return (size_t)nd_mtiles(ND_CONV3, cout) * nd_kblocks(cin) * 12 * 256 + (size_t)nd_mtiles(ND_CONV3, cout) * 32;
+}
+
+int nd_w1d_pack(int kind, int cin, int cout, const float *w, const float *bias, float *packed) {
+    if (kind != ND_CONV3 && kind != ND_CONVT3) ND_FAIL(ND_EINVAL, "w1d: 3x3 layers only");
+    const int MT = nd_mtiles(ND_CONV3, cout), KB = nd_kblocks(cin);
+    auto tap = [&](int co, int ci, int ky, int kx) -> double {
+        if (co >= cout || ci >= cin) return 0.0;
+        return kind == ND_CONV3 ? w[(((size_t)co * cin + ci) * 3 + ky) * 3 + kx] : w[(((size_t)ci * cout + co) * 3 + (2 - ky)) * 3 + (2 - kx)];
+    };
+    for (int mt = 0; mt < MT; ++mt)
+        for (int kb = 0; kb < KB; ++kb)
+            for (int ky = 0; ky < 3; ++ky)
+                for (int xi = 0; xi < 4; ++xi) {
+                    float *dst = packed + (((size_t)mt * KB + kb) * 12 + ky * 4 + xi) * 256;
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 4; ++e) {
+                            const int co = mt * 32 + (lane & 31), ci = 8 * kb + 4 * (lane >> 5) + e;   // A fragment map of conv_qp (pack.hip)
+                            const double g0 = tap(co, ci, ky, 0), g1 = tap(co, ci, ky, 1), g2 = tap(co, ci, ky, 2);
+                            const double u = xi == 0 ? g0 : (xi == 1 ? 0.5 * (g0 + g1 + g2) : (xi == 2 ? 0.5 * (g0 - g1 + g2) : g2));
+                            dst[lane * 4 + e] = (float)u;
+                        }
+                }
+    float *b = packed + (size_t)MT * KB * 12 * 256;
+    for (int i = 0; i < MT * 32; ++i) b[i] = (bias && i < cout) ? bias[i] : 0.f;
+    return ND_OK;
+}
+
+bool nd_w1d_applicable(const QpBuf &in) { return in.dt == ND_F32 && in.Wb >= 4 && (in.Wb % 2) == 0; }
+
+// d: the layer as for nd_launch_conv (CONV3 / CONVT3, fp32, no pre-activation copy); d.wpk = nd_w1d_pack blob
+int nd_launch_conv_w1d(const ConvDesc &d, hipStream_t stream) {
+    if ((d.kind != ND_CONV3 && d.kind != ND_CONVT3) || d.in.dt != ND_F32 || d.out.dt != ND_F32) ND_FAIL(ND_EINVAL, "w1d: fp32 3x3 layers only");
+    if (!nd_w1d_applicable(d.in)) ND_FAIL(ND_EINVAL, "w1d: rows must hold an even number of pixels (Wb = %d)", d.in.Wb);
+    if (d.pre || d.in_plane0) ND_FAIL(ND_EINVAL, "w1d: inference only");
+    if (d.cout % 4) ND_FAIL(ND_EINVAL, "w1d: cout must be a multiple of 4");
+    const int KB = nd_kblocks(d.cin);
+    if (d.in.planes < 2 * KB) ND_FAIL(ND_EINVAL, "w1d: input buffer has %d planes, needs %d", d.in.planes, 2 * KB);
+    const int Hv = d.in.Hb - 2, Wpx = d.in.Wb - 2, Wp = Wpx / 2;
+    if (d.out.Hb != Hv + 2 * d.out.pad || d.out.Wb != Wpx + 2 * d.out.pad || d.out.B != d.in.B) ND_FAIL(ND_EINVAL, "w1d: destination does not fit the result");
+    if (d.out_plane0 + d.cout / 4 > d.out.planes) ND_FAIL(ND_EINVAL, "w1d: destination planes overflow");
+    if (d.in.used() >= (1L << 31)) ND_FAIL(ND_EINVAL, "w1d: input too large for int32 indexing");
+
+    static int cus[16] = {0}, lds_set[16] = {0};
+    int dev = 0;
+    ND_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) ND_FAIL(ND_EINVAL, "w1d: device index %d", dev);
+    if (!cus[dev]) {
+        hipDeviceProp_t prop;
+        ND_HIP(hipGetDeviceProperties(&prop, dev));
+        cus[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    bool cross = true;
+    int G = (w1d_span(d.in, true) + 63) / 64;
+    if (w1d_lds(G) > 160 * 1024) {
+        cross = false;
+        G = (w1d_span(d.in, false) + 63) / 64;
+    }
+    const size_t lds = w1d_lds(G);
+    if (lds > 160 * 1024) ND_FAIL(ND_EINVAL, "w1d: %zu B of LDS needed (row width %d too large)", lds, d.in.Wb);
+    auto fn = conv_w1d<kW1dMR, kW1dWM, kW1dWN, kW1dStages>;
+    if ((int)lds > lds_set[dev]) {
+        ND_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set[dev] = (int)lds;
+    }
+
+    ConvParams p = {};
+    p.in = (const f32x4 *)d.in.base;
+    p.wpk = d.wpk;
+    p.bias = d.bias;
+    p.out = (f32x4 *)d.out.base;
+    p.in_plane = d.in.np();
+    p.out_plane = d.out.np();
+    p.nimg = d.in.B;
+    p.P = d.in.Hb * d.in.Wb;
+    p.Wb = d.in.Wb;
+    p.Hv = Hv;
+    p.Wv = Wp;              // pairs per row
+    p.PV = Hv * Wp;         // pairs per image
+    p.G = G;
+    p.stride = 1;
+    p.ioff = 0;
+    p.pre = nullptr;
+    p.KB = KB;
+    p.M = d.cout;
+    p.cout = d.cout;
+    p.Po = d.out.Hb * d.out.Wb;
+    p.Wo = d.out.Wb;
+    p.opad = d.out.pad;
+    p.out_plane0 = d.out_plane0;
+    p.act = d.act;
+    p.slope = d.slope;
+    p.slope_dev = d.slope_dev;
+    if (cross) {
+        p.tpi = 0;
+        p.n_tiles_n = (int)(((long)p.nimg * p.PV + kW1dPairs - 1) / kW1dPairs);
+    } else {
+        p.tpi = (p.PV + kW1dPairs - 1) / kW1dPairs;
+        p.n_tiles_n = p.tpi * p.nimg;
+    }
+    p.n_tiles_m = (d.cout + kW1dMblk - 1) / kW1dMblk;
+    p.tiles_per_problem = p.n_tiles_n * p.n_tiles_m;
+    const long ntiles = p.tiles_per_problem;
+    const long slots = cus[dev];
+    const long cap = d.part ? (long)(d.part_bytes / ((size_t)kW1dMblk * 2 * kW1dPairs * 4)) : 0;
+    int first, S, cps;
+    nd_plan_split(ntiles, KB, slots, cap, &first, &S, &cps);
+    p.split_first = first;
+    p.S = S;
+    p.cps = cps;
+    p.nitems = (int)(first + (ntiles - first) * S);
+    p.part = (f32x4 *)d.part;
+    const long grid = p.nitems < slots ? p.nitems : slots;
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(64 * kW1dWM * kW1dWN), lds, stream, p);
+    if (first < ntiles) {
+        // the finish kernel works in pixels: a tile of n pairs is 2n consecutive compact pixels
+        ConvParams f = p;
+        f.Wv = Wpx;
+        f.PV = Hv * Wpx;
+        ND_TRY(nd_launch_split_finish(f, (int)(ntiles - first), kW1dMblk, 2 * kW1dPairs, 0, ND_F32, stream));
+    }
+    ND_HIP(hipGetLastError());
+    return ND_OK;
+}

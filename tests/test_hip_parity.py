@@ -178,6 +178,9 @@ def test_layer_split_k(dev, case, dtype):
 
 WINO_CASES = [
     # kind, B, cin, cout, H, W, act
+    ("conv3", 1, 3, 64, 40, 40, "PReLU"),        # first layer: 3 channels padded to one K block (1-D form only: Cin % 16)
+    ("conv3", 3, 64, 64, 70, 66, "PReLU"),       # several tiles, rows shorter than a tile
+    ("convT3", 2, 64, 64, 266, 266, "PReLU"),    # full-width rows of a 264-pixel tile (largest LDS halo image)
     ("conv3", 2, 16, 32, 10, 12, "PReLU"),       # Cout < 128: the generic 1-tap variant
     ("conv3", 3, 64, 128, 21, 19, "PReLU"),      # odd output sizes: partial tiles masked
     ("convT3", 2, 32, 256, 11, 11, "PReLU"),     # transposed layer (flipped taps, zero border), 256-row GEMM tile
@@ -188,16 +191,20 @@ WINO_CASES = [
 
 
 @pytest.mark.parametrize("case", WINO_CASES, ids=lambda c: "-".join(str(v) for v in c))
-@pytest.mark.parametrize("tile", [2, 4])
+@pytest.mark.parametrize("tile", [1, 2, 4])
 def test_layer_winograd(dev, case, tile):
     """Winograd F(t x t, 3 x 3) form of a 3x3 layer (csrc/winograd.hip: input transform, 16 / 36 batched GEMMs in one launch,
     output transform) against torch and against the direct kernel."""
     kind, B, cin, cout, H, W, act = case
+    if tile == 1 and W % 2:      # tile 1 = the 1-D F(2,3) form fused into the implicit-GEMM kernel: even rows only
+        W += 1
     x = rnd((B, cin, H, W), 1)
     bound = 1.0 / np.sqrt(cin * 9)
     wshape = (cout, cin, 3, 3) if kind == "conv3" else (cin, cout, 3, 3)
     w = rnd(wshape, 2, bound * 1.7)
     b = rnd((cout,), 3, 0.2)
+    if tile != 1 and cin % 16:
+        pytest.skip("the three-pass form needs Cin % 16 == 0")
     lib = _lib.load()
     k = _lib.KIND[kind]
     nbytes = lib.nd_winograd_packed_bytes(tile, cin, cout)
