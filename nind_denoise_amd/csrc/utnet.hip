@@ -42,6 +42,7 @@ extern "C" int nd_utnet_pack_weights(int funit, int dtype, const float *const *t
         } else {
             nd_pack_layer(l.kind, ci, co, dtype, tensors[wi], tensors[bi], blob + bl.off[i]);
             if (bl.woff[i]) ND_TRY(nd_wino_pack(kWinoTile, l.kind, ci, co, tensors[wi], tensors[bi], blob + bl.woff[i]));
+            if (bl.w1off[i]) ND_TRY(nd_w1d_pack(l.kind, ci, co, tensors[wi], tensors[bi], blob + bl.w1off[i]));
         }
         if (l.prelu >= 0) {
             // activation module sits right after the layer in its Sequential: "<seq>.<k+1>.weight"

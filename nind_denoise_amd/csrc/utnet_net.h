@@ -83,7 +83,8 @@ inline bool wino_layer(const LayerSpec &l, int f, int dt) {
 // float offsets of every layer inside the packed blob
 struct BlobLayout {
     size_t off[kNumLayers];
-    size_t woff[kNumLayers];   // Winograd form of the layer (0: none)
+    size_t woff[kNumLayers];   // Winograd F(4x4,3x3) form of the layer (0: none)
+    size_t w1off[kNumLayers];  // 1-D F(2,3) form fused into the implicit-GEMM kernel (conv_w1d.hip): the other fp32 3x3 layers
     size_t total;
 };
 BlobLayout blob_layout(int f, int dt, bool with_wino = true) {
@@ -102,6 +103,12 @@ BlobLayout blob_layout(int f, int dt, bool with_wino = true) {
         if (with_wino && wino_layer(kLayers[i], f, dt)) {
             b.woff[i] = o;
             o += (nd_wino_packed_floats(kWinoTile, lcin(kLayers[i], f), lcout(kLayers[i], f)) + 63) / 64 * 64;
+        }
+        b.w1off[i] = 0;
+        const LayerSpec &l = kLayers[i];
+        if (with_wino && dt == ND_F32 && (l.kind == ND_CONV3 || l.kind == ND_CONVT3) && !b.woff[i]) {
+            b.w1off[i] = o;
+            o += (nd_w1d_packed_floats(lcin(l, f), lcout(l, f)) + 63) / 64 * 64;
         }
     }
     b.total = o;
@@ -256,6 +263,13 @@ int run_stack(int f, int act, int dt, const float *blob, const Plan &pl, hipStre
         d.variant = -1;
         d.part = pl.split;
         d.part_bytes = kSplitScratchBytes;
+        if (!pre && bl.w1off[st.layer] && nd_conv_winograd_enabled() && nd_w1d_applicable(d.in)) {
+            // narrow layer: 1-D F(2,3) along x inside the implicit-GEMM kernel (2/3 of the MFMAs)
+            d.wpk = blob + bl.w1off[st.layer];
+            d.bias = d.wpk + (size_t)nd_mtiles(ND_CONV3, d.cout) * nd_kblocks(d.cin) * 12 * 256;
+            ND_TRY(nd_launch_conv_w1d(d, s));
+            continue;
+        }
         if (!pre && bl.woff[st.layer] && nd_conv_winograd_enabled()) {
             // Winograd form, kWinoChunk images per pass (views of the same buffers)
             d.wpk = blob + bl.woff[st.layer];

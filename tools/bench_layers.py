@@ -84,8 +84,10 @@ def main():
             print(f"{name:10s} {kind:8s} {cin:4d}->{cout:4d} {h:3d}^2  v{v:<2d} {names[v] if v >= 0 else 'auto':34s} {ms.value:8.4f} ms {tf:7.2f} TF", flush=True)
             tot.setdefault(v, 0.0)
             tot[v] += ms.value
-            if v == -1 and args.winograd and kind in ("conv3", "convT3") and cin % 16 == 0 and args.dtype == "f32":
-                for tile in (2, 4):
+            if v == -1 and args.winograd and kind in ("conv3", "convT3") and args.dtype == "f32":
+                for tile in (1, 4):      # 1 = 1-D F(2,3) fused into the implicit-GEMM kernel, 4 = three-pass F(4x4,3x3)
+                    if tile != 1 and cin % 16:
+                        continue
                     rc = lib.nd_winograd_bench(tile, k, args.batch, cin, cout, h, h, args.iters, ws.data_ptr(), ws.numel(),
                                                _lib.stream_ptr(dev), ms)
                     if rc != 0:
