@@ -105,8 +105,9 @@ def conv_stack_profile(net, cs, batch, dev, reps=3):
 
 
 def executed_flop(name, flop, cs, batch, funit, dtype):
-    """MFMA-executed FLOP of one conv-stack step: the algorithmic FLOP for the direct layers, 36 GEMMs of Cout x Cin x tiles for
-    the layers that run in Winograd F(4x4, 3x3) form (csrc/utnet_net.h: wino_layer -- fp32, 3x3, Cin and Cout >= 128)."""
+    """MFMA-executed FLOP of one conv-stack step (csrc/utnet_net.h: wino_layer): 36 GEMMs of Cout x Cin x tiles for the 3x3 layers in
+    three-pass Winograd F(4x4,3x3) form, 18 weight planes per group of 4 pixels for the ones in fused 1-D F(4,3) form, the
+    algorithmic FLOP for everything else."""
     import math
     f, h = funit, cs + 4
     shapes = {}
@@ -126,9 +127,10 @@ def executed_flop(name, flop, cs, batch, funit, dtype):
     if name not in shapes or dtype != "f32":
         return flop
     ci, co, hout = shapes[name]
-    if ci < 128 or co < 128:
-        return flop
-    return 36 * 2.0 * ci * co * math.ceil(hout / 4) ** 2 * batch
+    if ci >= 128 and co >= 128 and ci * co >= 128 * 256:
+        return 36 * 2.0 * ci * co * math.ceil(hout / 4) ** 2 * batch            # three-pass F(4x4,3x3): 36 GEMMs
+    cip = (ci + 7) // 8 * 8
+    return 3 * 6 * 2.0 * cip * co * hout * math.ceil(hout / 4) * batch           # 1-D F(4,3) in the implicit-GEMM kernel: 18 planes per 4 pixels
 
 
 def pmc_traffic(cs, batch, funit):
@@ -296,8 +298,9 @@ def main():
             out["roofline"] = {
                 "bound": "mfma",
                 "kernel": f"conv_qp<{args.dtype}>: the 22 weighted layers of the UtNet conv stack per tile batch"
-                          + (" -- direct 3x3 implicit GEMM (5 layers), 36 batched 1-tap GEMMs per Winograd F(4x4,3x3) layer (13 layers, "
-                             "layer time includes the two transform passes), 2x2-s2 transposed (4 layers)" if wino else ""),
+                          + (" -- 1-D Winograd F(4,3) inside the 3x3 implicit-GEMM kernel (7 layers), 36 batched 1-tap GEMMs per three-pass "
+                             "Winograd F(4x4,3x3) layer (11 layers, layer time includes the two transform passes), 2x2-s2 transposed "
+                             "(4 layers)" if wino else ""),
                 "achieved": round(achieved, 3),
                 "peak": PEAK_MFMA_TFLOPS[args.dtype],
                 "unit": "TFLOP/s",

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256) void k_split_finish(ConvParams p, int mblk, in
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = p.act <= ND_ACT_PRELU ? (acc[e] > 0.f ? acc[e] : acc[e] * slope) : apply_act(acc[e], p.act, slope);
         const int y = r / p.Wv, x = r - y * p.Wv;
+        if (p.wpx && x >= p.wpx) continue;
         int co = m4;
         long pix;
         if (up) {
@@ -326,6 +327,7 @@ int nd_launch_conv(const ConvDesc &d, hipStream_t stream) {
     }
     p.n_tiles_m = (M + V.mblk - 1) / V.mblk;
     p.tiles_per_problem = p.n_tiles_n * p.n_tiles_m;
+    p.wpx = 0;
     p.in_bs = d.in_bs;
     p.out_bs = d.out_bs;
     p.w_bs = (long)d.w_bs;

@@ -7,20 +7,68 @@
 //     m_xi  += U[ky][xi] (Cout x Cin) * v_xi,   U[ky] = (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2) of that kernel row      (MFMA)
 //     Y[x0] = m0+m1+m2,  Y[x0+1] = m1-m2-m3                                                   (in registers, epilogue)
 // 12 weight planes and 4 accumulator sets per pair instead of 9 taps x 2 pixels: 2/3 of the MFMAs, the same LDS-DMA bytes.
-// An N tile enumerates valid pixel PAIRS (rows have an even number of valid pixels: 16k+56 tile sizes guarantee it at the levels
-// this is used for; the launcher refuses odd rows).  Result differs from the direct kernel by fp32 re-association (~1e-6).
+// T = 4 is the same with F(4,3): groups of 4 pixels, 6 positions, 18 weight planes, 6 accumulator sets (one 32-row tile per
+// wave instead of two): 1/2 of the MFMAs.  An N tile enumerates pixel GROUPS row by row; a group hanging over the row end takes
+// zeros for the inputs only its out-of-row outputs need (so a tile's bits never depend on what lies behind the row: the next
+// image of the batch or slack) and does not store those outputs.  Result differs from the direct kernel by fp32
+// re-association (~1e-6 / ~5e-6).
 #include "conv_qp.inc"
 
 namespace {
 
-// MR : 32-row tiles per wave (x 4 position sets);  one 32-pair group per wave;  WM x WN waves
-template <int MR, int WM, int WN, int NSTAGE>
+template <int T> struct W1;
+template <> struct W1<2> {
+    __device__ static void in(const f32x4 *d, f32x4 *v) {
+        v[0] = d[0] - d[2];
+        v[1] = d[1] + d[2];
+        v[2] = d[2] - d[1];
+        v[3] = d[1] - d[3];
+    }
+    __device__ static void out(const float *m, float *y) {
+        y[0] = m[0] + m[1] + m[2];
+        y[1] = m[1] - m[2] - m[3];
+    }
+    static void g(const double *w, double *u) {
+        u[0] = w[0];
+        u[1] = 0.5 * (w[0] + w[1] + w[2]);
+        u[2] = 0.5 * (w[0] - w[1] + w[2]);
+        u[3] = w[2];
+    }
+};
+template <> struct W1<4> {
+    __device__ static void in(const f32x4 *d, f32x4 *v) {
+        v[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+        v[1] = -4.f * (d[1] + d[2]) + d[3] + d[4];
+        v[2] = 4.f * (d[1] - d[2]) - d[3] + d[4];
+        v[3] = -2.f * d[1] - d[2] + 2.f * d[3] + d[4];
+        v[4] = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
+        v[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+    }
+    __device__ static void out(const float *m, float *y) {
+        y[0] = m[0] + m[1] + m[2] + m[3] + m[4];
+        y[1] = m[1] - m[2] + 2.f * (m[3] - m[4]);
+        y[2] = m[1] + m[2] + 4.f * (m[3] + m[4]);
+        y[3] = m[1] - m[2] + 8.f * (m[3] - m[4]) + m[5];
+    }
+    static void g(const double *w, double *u) {
+        u[0] = w[0] / 4;
+        u[1] = -(w[0] + w[1] + w[2]) / 6;
+        u[2] = -(w[0] - w[1] + w[2]) / 6;
+        u[3] = w[0] / 24 + w[1] / 12 + w[2] / 6;
+        u[4] = w[0] / 24 - w[1] / 12 + w[2] / 6;
+        u[5] = w[2];
+    }
+};
+
+// T : output pixels per group (2 | 4);  MR : 32-row tiles per wave (x T+2 position sets);  one 32-group tile per wave;  WM x WN waves
+template <int T, int MR, int WM, int WN, int NSTAGE>
 __global__ __launch_bounds__(64 * WM * WN) void conv_w1d(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NP = T + 2;               // positions
     constexpr int NW = WM * WN;
     constexpr int MTB = MR * WM;
-    constexpr int NBLK = 32 * WN;           // pixel pairs per workgroup tile
-    constexpr int TAPS = 12;                // weight planes per K block: 3 kernel rows x 4 positions
+    constexpr int NBLK = 32 * WN;           // pixel groups per workgroup tile
+    constexpr int TAPS = 3 * NP;            // weight planes per K block: 3 kernel rows x positions
     constexpr int WBYTES = MTB * TAPS * 1024;
 
     const int lane = threadIdx.x & 63;
@@ -81,9 +129,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_w1d(ConvParams p) {
         }
         return ok;
     };
-    auto q_of = [&](int img, int r) -> long {   // linear input index of the pair's first pixel
+    auto q_of = [&](int img, int r) -> long {   // linear input index of the group's first pixel
         const int y = r / p.Wv;
-        return (long)img * p.P + (long)y * p.Wb + 2 * (r - y * p.Wv);
+        return (long)img * p.P + (long)y * p.Wb + T * (r - y * p.Wv);
     };
     auto tile_q0 = [&](int nb) -> long {
         int img, r;
@@ -131,18 +179,21 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_w1d(ConvParams p) {
     };
 
     const int aOff = (wm * MR) * TAPS * 1024 + lane * 16;
+    int keep = NP;   // inputs d[0 .. keep) of this lane's group feed in-row outputs (NP unless the group hangs over the row end)
     auto lane_offset = [&](int w) -> int {
         const int nb = decode(w).tile / p.n_tiles_m;
         int img, r;
         pair_of(nb, wn * 32 + j, img, r);
+        const int left = p.wpx - T * (r % p.Wv);
+        keep = left + 2 < NP ? left + 2 : NP;
         return WBYTES + h * planeB + (int)(q_of(img, r) - tile_q0(nb)) * 16;
     };
     int bOff = lane_offset(vb);
     const int rowB = p.Wb * 16;
 
-    f32x16 acc[4][MR];
+    f32x16 acc[NP][MR];
 #pragma unroll
-    for (int x = 0; x < 4; ++x)
+    for (int x = 0; x < NP; ++x)
 #pragma unroll
         for (int m = 0; m < MR; ++m)
 #pragma unroll
@@ -150,14 +201,19 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_w1d(ConvParams p) {
 
     const float slope = p.act == ND_ACT_NONE ? 1.f : (p.slope_dev ? *p.slope_dev : p.slope);
 
-    // combine the four position accumulators of (mr, g) into the two pixels' sums (clears them)
-    auto combine = [&](int mr, int g, f32x4 &y0, f32x4 &y1) {
+    // combine the position accumulators of (mr, g) into the T pixels' sums (clears them)
+    auto combine = [&](int mr, int g, f32x4 *y) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float m0 = acc[0][mr][4 * g + e], m1 = acc[1][mr][4 * g + e], m2 = acc[2][mr][4 * g + e], m3 = acc[3][mr][4 * g + e];
-            y0[e] = m0 + m1 + m2;
-            y1[e] = m1 - m2 - m3;
-            acc[0][mr][4 * g + e] = acc[1][mr][4 * g + e] = acc[2][mr][4 * g + e] = acc[3][mr][4 * g + e] = 0.f;
+            float m[NP], o[T];
+#pragma unroll
+            for (int x = 0; x < NP; ++x) {
+                m[x] = acc[x][mr][4 * g + e];
+                acc[x][mr][4 * g + e] = 0.f;
+            }
+            W1<T>::out(m, o);
+#pragma unroll
+            for (int i = 0; i < T; ++i) y[i][e] = o[i];
         }
     };
 
@@ -166,7 +222,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_w1d(ConvParams p) {
         int bi, r;
         const bool valid = pair_of(nb, wn * 32 + j, bi, r);
         const int y = r / p.Wv, xp = r - y * p.Wv;
-        const long pix = (long)bi * p.Po + (long)(y + p.opad) * p.Wo + 2 * xp + p.opad;
+        const long pix = (long)bi * p.Po + (long)(y + p.opad) * p.Wo + T * xp + p.opad;
+        const int left = p.wpx - T * xp;   // valid pixels of this group (the last group of a row may hang over its end)
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
@@ -174,33 +231,32 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_w1d(ConvParams p) {
                 const int m8 = ((mb * MTB + wm * MR + mr) * 32) + 8 * g;
                 const f32x8 b8 = sload8(p.bias + m8);
                 const int m4 = m8 + 4 * h;
-                f32x4 y0, y1;
-                combine(mr, g, y0, y1);
+                f32x4 yy[T];
+                combine(mr, g, yy);
                 if (valid && m4 < p.M) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float bv = h ? b8[4 + e] : b8[e];
-                        y0[e] = apply_act(y0[e] + bv, p.act, slope);
-                        y1[e] = apply_act(y1[e] + bv, p.act, slope);
-                    }
                     f32x4 *dst = p.out + (long)(p.out_plane0 + (m4 >> 2)) * p.out_plane + pix;
-                    dst[0] = y0;
-                    dst[1] = y1;
+#pragma unroll
+                    for (int i = 0; i < T; ++i) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) yy[i][e] = apply_act(yy[i][e] + (h ? b8[4 + e] : b8[e]), p.act, slope);
+                        if (i < left) dst[i] = yy[i];
+                    }
                 }
             }
     };
-    // a K slice of a split tile: combined raw sums, tile-local [quad][pixel] layout of k_split_finish (2 * NBLK pixels)
+    // a K slice of a split tile: combined raw sums in the tile-local layout of k_split_finish,
+    // [channel quad][T * NBLK "pixels"] with pixel index = T * group + i (groups hanging over a row end keep their slots)
     auto epilogue_partial = [&](int slice) {
-        f32x4 *dst = p.part + (size_t)slice * (MTB * 8) * (2 * NBLK);
+        f32x4 *dst = p.part + (size_t)slice * (MTB * 8) * (T * NBLK);
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                f32x4 y0, y1;
-                combine(mr, g, y0, y1);
-                f32x4 *d2 = dst + (size_t)((wm * MR + mr) * 8 + 2 * g + h) * (2 * NBLK) + 2 * (wn * 32 + j);
-                d2[0] = y0;
-                d2[1] = y1;
+                f32x4 yy[T];
+                combine(mr, g, yy);
+                f32x4 *d2 = dst + (size_t)((wm * MR + mr) * 8 + 2 * g + h) * (T * NBLK) + T * (wn * 32 + j);
+#pragma unroll
+                for (int i = 0; i < T; ++i) d2[i] = yy[i];
             }
     };
 
@@ -217,22 +273,28 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_w1d(ConvParams p) {
         fill_next();
         const char *sb = smem + c_stage * stageB;
         const char *bp = sb + bOff;
-        f32x4 d[2][4];
+        f32x4 d[2][NP];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) d[0][i] = *(const f32x4 *)(bp + i * 16);
+        for (int i = 0; i < NP; ++i) d[0][i] = *(const f32x4 *)(bp + i * 16);
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             if (ky + 1 < 3) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) d[(ky + 1) & 1][i] = *(const f32x4 *)(bp + (ky + 1) * rowB + i * 16);
+                for (int i = 0; i < NP; ++i) d[(ky + 1) & 1][i] = *(const f32x4 *)(bp + (ky + 1) * rowB + i * 16);
             }
-            const f32x4 *dd = d[ky & 1];
-            const f32x4 v[4] = {dd[0] - dd[2], dd[1] + dd[2], dd[2] - dd[1], dd[1] - dd[3]};
+            if constexpr (T > 2) {   // (T = 2: the one over-read input only reaches the output that is not stored)
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int xi = 0; xi < 4; ++xi) {
+                for (int i = 3; i < NP; ++i)
+                    if (i >= keep) d[ky & 1][i] = zero;
+            }
+            f32x4 v[NP];
+            W1<T>::in(d[ky & 1], v);
+#pragma unroll
+            for (int xi = 0; xi < NP; ++xi) {
                 f32x4 a[MR];
 #pragma unroll
-                for (int mr = 0; mr < MR; ++mr) a[mr] = *(const f32x4 *)(sb + aOff + (mr * TAPS + ky * 4 + xi) * 1024);
+                for (int mr = 0; mr < MR; ++mr) a[mr] = *(const f32x4 *)(sb + aOff + (mr * TAPS + ky * NP + xi) * 1024);
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -256,30 +318,38 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_w1d(ConvParams p) {
     }
 }
 
-constexpr int kW1dMR = 2, kW1dWM = 1, kW1dWN = 8, kW1dStages = 2;
-constexpr int kW1dMblk = 32 * kW1dMR * kW1dWM, kW1dPairs = 32 * kW1dWN;
+// workgroup shapes: 64 output channels x 256 groups (T = 2: 512 pixels, 2 x 32 rows per wave; T = 4: 1024 pixels... see below)
+struct W1Shape { int T, mblk, groups, threads, taps; };
+constexpr int kW1dStages = 2;
+//   T = 2: MR 2, WM 1, WN 8 -> 64 rows x 256 pairs (512 pixels), 8 accumulator tiles per wave
+//   T = 4: MR 1, WM 2, WN 4 -> 64 rows x 128 quads (512 pixels), 6 accumulator tiles per wave
+constexpr W1Shape kShape2 = {2, 64, 256, 512, 12}, kShape4 = {4, 64, 128, 512, 18};
+const W1Shape &shape_of(int T) { return T == 4 ? kShape4 : kShape2; }
 
-// input pixels spanned by one N tile (+ halo): n pairs = 2n valid pixels, row and image gaps, 2 rows + 4 pixels of halo
-int w1d_span(const QpBuf &in, bool cross) {
-    const int Hv = in.Hb - 2, Wp = (in.Wb - 2) / 2, n = kW1dPairs;
-    long span = 2L * n + (long)(in.Wb - 2 * Wp) * ((n - 1) / Wp + 1);
-    if (cross) span += (long)(in.Hb * in.Wb - Hv * in.Wb) * ((n - 1) / (Hv * Wp) + 1);
+// input pixels spanned by one N tile (+ halo): n groups of T pixels row by row, row and image gaps, 2 rows + T+2 pixels of halo
+int w1d_span(const W1Shape &sh, const QpBuf &in, bool cross) {
+    const int Hv = in.Hb - 2, Wv = in.Wb - 2, Wg = (Wv + sh.T - 1) / sh.T, n = sh.groups;
+    const long rows = (n - 1) / Wg + 2;                 // rows an N tile can touch
+    long span = rows * in.Wb;
+    if ((long)sh.T * n + in.Wb < span) span = (long)sh.T * n + (long)(in.Wb - sh.T * Wg > 0 ? in.Wb - sh.T * Wg : 0) * rows + in.Wb;
+    if (cross) span += (long)(in.Hb * in.Wb - Hv * in.Wb) * ((n - 1) / (Hv * Wg) + 1);
     const long whole = (long)in.B * in.Hb * in.Wb;
     if (cross && span > whole) span = whole;
-    return (int)(span + 2 * in.Wb + 4);
+    return (int)(span + 2 * in.Wb + sh.T + 2);
 }
-size_t w1d_lds(int G) { return (size_t)kW1dStages * ((size_t)(kW1dMblk / 32) * 12 * 1024 + (size_t)2 * G * 1024); }
+size_t w1d_lds(const W1Shape &sh, int G) { return (size_t)kW1dStages * ((size_t)(sh.mblk / 32) * sh.taps * 1024 + (size_t)2 * G * 1024); }
 
 }  // namespace
 
-// packed layout: [32-row tile][K block][12 = ky*4 + xi][lane][4] + bias[mtiles*32]   (as pack.hip, 12 planes instead of 9 taps)
-size_t nd_w1d_packed_floats(int cin, int cout) {
-    return (size_t)nd_mtiles(ND_CONV3, cout) * nd_kblocks(cin) * 12 * 256 + (size_t)nd_mtiles(ND_CONV3, cout) * 32;
+// packed layout: [32-row tile][K block][3 * (T+2) planes = ky*(T+2) + xi][lane][4] + bias[mtiles*32]   (as pack.hip)
+size_t nd_w1d_packed_floats(int T, int cin, int cout) {
+    return (size_t)nd_mtiles(ND_CONV3, cout) * nd_kblocks(cin) * 3 * (T + 2) * 256 + (size_t)nd_mtiles(ND_CONV3, cout) * 32;
 }
 
-int nd_w1d_pack(int kind, int cin, int cout, const float *w, const float *bias, float *packed) {
+int nd_w1d_pack(int T, int kind, int cin, int cout, const float *w, const float *bias, float *packed) {
+    if (T != 2 && T != 4) ND_FAIL(ND_EINVAL, "w1d: group size must be 2 or 4");
     if (kind != ND_CONV3 && kind != ND_CONVT3) ND_FAIL(ND_EINVAL, "w1d: 3x3 layers only");
-    const int MT = nd_mtiles(ND_CONV3, cout), KB = nd_kblocks(cin);
+    const int MT = nd_mtiles(ND_CONV3, cout), KB = nd_kblocks(cin), NP = T + 2;
     auto tap = [&](int co, int ci, int ky, int kx) -> double {
         if (co >= cout || ci >= cin) return 0.0;
         return kind == ND_CONV3 ? w[(((size_t)co * cin + ci) * 3 + ky) * 3 + kx] : w[(((size_t)ci * cout + co) * 3 + (2 - ky)) * 3 + (2 - kx)];
@@ -287,37 +357,54 @@ int nd_w1d_pack(int kind, int cin, int cout, const float *w, const float *bias, 
     for (int mt = 0; mt < MT; ++mt)
         for (int kb = 0; kb < KB; ++kb)
             for (int ky = 0; ky < 3; ++ky)
-                for (int xi = 0; xi < 4; ++xi) {
-                    float *dst = packed + (((size_t)mt * KB + kb) * 12 + ky * 4 + xi) * 256;
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int e = 0; e < 4; ++e) {
-                            const int co = mt * 32 + (lane & 31), ci = 8 * kb + 4 * (lane >> 5) + e;   // A fragment map of conv_qp (pack.hip)
-                            const double g0 = tap(co, ci, ky, 0), g1 = tap(co, ci, ky, 1), g2 = tap(co, ci, ky, 2);
-                            const double u = xi == 0 ? g0 : (xi == 1 ? 0.5 * (g0 + g1 + g2) : (xi == 2 ? 0.5 * (g0 - g1 + g2) : g2));
-                            dst[lane * 4 + e] = (float)u;
-                        }
-                }
-    float *b = packed + (size_t)MT * KB * 12 * 256;
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 4; ++e) {
+                        const int co = mt * 32 + (lane & 31), ci = 8 * kb + 4 * (lane >> 5) + e;   // A fragment map of conv_qp (pack.hip)
+                        const double g[3] = {tap(co, ci, ky, 0), tap(co, ci, ky, 1), tap(co, ci, ky, 2)};
+                        double u[6];
+                        if (T == 2) W1<2>::g(g, u); else W1<4>::g(g, u);
+                        for (int xi = 0; xi < NP; ++xi)
+                            packed[(((size_t)mt * KB + kb) * 3 * NP + ky * NP + xi) * 256 + lane * 4 + e] = (float)u[xi];
+                    }
+    float *b = packed + (size_t)MT * KB * 3 * NP * 256;
     for (int i = 0; i < MT * 32; ++i) b[i] = (bias && i < cout) ? bias[i] : 0.f;
     return ND_OK;
 }
 
-bool nd_w1d_applicable(const QpBuf &in) { return in.dt == ND_F32 && in.Wb >= 4 && (in.Wb % 2) == 0; }
+static int w1d_geometry(const W1Shape &sh, const QpBuf &in, bool *cross, size_t *lds) {
+    *cross = true;
+    int G = (w1d_span(sh, in, true) + 63) / 64;
+    if (w1d_lds(sh, G) > 160 * 1024) {
+        *cross = false;
+        G = (w1d_span(sh, in, false) + 63) / 64;
+    }
+    *lds = w1d_lds(sh, G);
+    return G;
+}
+// the stage images of a row this wide fit the LDS (cs >= ~400 at full resolution does not for T = 4: fall back to T = 2 / direct)
+bool nd_w1d_fits(int T, const QpBuf &in) {
+    bool cross;
+    size_t lds;
+    w1d_geometry(shape_of(T), in, &cross, &lds);
+    return (T == 2 || T == 4) && in.dt == ND_F32 && in.Hb >= 3 && in.Wb >= 3 && lds <= 160 * 1024;
+}
 
-// d: the layer as for nd_launch_conv (CONV3 / CONVT3, fp32, no pre-activation copy); d.wpk = nd_w1d_pack blob
-int nd_launch_conv_w1d(const ConvDesc &d, hipStream_t stream) {
+// d: the layer as for nd_launch_conv (CONV3 / CONVT3, fp32, no pre-activation copy); d.wpk = nd_w1d_pack blob of the same T
+int nd_launch_conv_w1d(int T, const ConvDesc &d, hipStream_t stream) {
+    if (T != 2 && T != 4) ND_FAIL(ND_EINVAL, "w1d: group size must be 2 or 4");
     if ((d.kind != ND_CONV3 && d.kind != ND_CONVT3) || d.in.dt != ND_F32 || d.out.dt != ND_F32) ND_FAIL(ND_EINVAL, "w1d: fp32 3x3 layers only");
-    if (!nd_w1d_applicable(d.in)) ND_FAIL(ND_EINVAL, "w1d: rows must hold an even number of pixels (Wb = %d)", d.in.Wb);
     if (d.pre || d.in_plane0) ND_FAIL(ND_EINVAL, "w1d: inference only");
     if (d.cout % 4) ND_FAIL(ND_EINVAL, "w1d: cout must be a multiple of 4");
+    const W1Shape &sh = shape_of(T);
     const int KB = nd_kblocks(d.cin);
     if (d.in.planes < 2 * KB) ND_FAIL(ND_EINVAL, "w1d: input buffer has %d planes, needs %d", d.in.planes, 2 * KB);
-    const int Hv = d.in.Hb - 2, Wpx = d.in.Wb - 2, Wp = Wpx / 2;
+    const int Hv = d.in.Hb - 2, Wpx = d.in.Wb - 2, Wg = (Wpx + T - 1) / T;
+    if (Hv < 1 || Wpx < 1) ND_FAIL(ND_EINVAL, "w1d: input smaller than the kernel");
     if (d.out.Hb != Hv + 2 * d.out.pad || d.out.Wb != Wpx + 2 * d.out.pad || d.out.B != d.in.B) ND_FAIL(ND_EINVAL, "w1d: destination does not fit the result");
     if (d.out_plane0 + d.cout / 4 > d.out.planes) ND_FAIL(ND_EINVAL, "w1d: destination planes overflow");
     if (d.in.used() >= (1L << 31)) ND_FAIL(ND_EINVAL, "w1d: input too large for int32 indexing");
 
-    static int cus[16] = {0}, lds_set[16] = {0};
+    static int cus[16] = {0}, lds_set[16][2] = {{0}};
     int dev = 0;
     ND_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 16) ND_FAIL(ND_EINVAL, "w1d: device index %d", dev);
@@ -326,18 +413,14 @@ int nd_launch_conv_w1d(const ConvDesc &d, hipStream_t stream) {
         ND_HIP(hipGetDeviceProperties(&prop, dev));
         cus[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    bool cross = true;
-    int G = (w1d_span(d.in, true) + 63) / 64;
-    if (w1d_lds(G) > 160 * 1024) {
-        cross = false;
-        G = (w1d_span(d.in, false) + 63) / 64;
-    }
-    const size_t lds = w1d_lds(G);
+    bool cross;
+    size_t lds;
+    const int G = w1d_geometry(sh, d.in, &cross, &lds);
     if (lds > 160 * 1024) ND_FAIL(ND_EINVAL, "w1d: %zu B of LDS needed (row width %d too large)", lds, d.in.Wb);
-    auto fn = conv_w1d<kW1dMR, kW1dWM, kW1dWN, kW1dStages>;
-    if ((int)lds > lds_set[dev]) {
+    void (*fn)(ConvParams) = T == 4 ? conv_w1d<4, 1, 2, 4, kW1dStages> : conv_w1d<2, 2, 1, 8, kW1dStages>;
+    if ((int)lds > lds_set[dev][T == 4]) {
         ND_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set[dev] = (int)lds;
+        lds_set[dev][T == 4] = (int)lds;
     }
 
     ConvParams p = {};
@@ -351,8 +434,9 @@ int nd_launch_conv_w1d(const ConvDesc &d, hipStream_t stream) {
     p.P = d.in.Hb * d.in.Wb;
     p.Wb = d.in.Wb;
     p.Hv = Hv;
-    p.Wv = Wp;              // pairs per row
-    p.PV = Hv * Wp;         // pairs per image
+    p.Wv = Wg;              // groups per row
+    p.PV = Hv * Wg;         // groups per image
+    p.wpx = Wpx;            // valid pixels per row
     p.G = G;
     p.stride = 1;
     p.ioff = 0;
@@ -369,16 +453,16 @@ int nd_launch_conv_w1d(const ConvDesc &d, hipStream_t stream) {
     p.slope_dev = d.slope_dev;
     if (cross) {
         p.tpi = 0;
-        p.n_tiles_n = (int)(((long)p.nimg * p.PV + kW1dPairs - 1) / kW1dPairs);
+        p.n_tiles_n = (int)(((long)p.nimg * p.PV + sh.groups - 1) / sh.groups);
     } else {
-        p.tpi = (p.PV + kW1dPairs - 1) / kW1dPairs;
+        p.tpi = (p.PV + sh.groups - 1) / sh.groups;
         p.n_tiles_n = p.tpi * p.nimg;
     }
-    p.n_tiles_m = (d.cout + kW1dMblk - 1) / kW1dMblk;
+    p.n_tiles_m = (d.cout + sh.mblk - 1) / sh.mblk;
     p.tiles_per_problem = p.n_tiles_n * p.n_tiles_m;
     const long ntiles = p.tiles_per_problem;
     const long slots = cus[dev];
-    const long cap = d.part ? (long)(d.part_bytes / ((size_t)kW1dMblk * 2 * kW1dPairs * 4)) : 0;
+    const long cap = d.part ? (long)(d.part_bytes / ((size_t)sh.mblk * T * sh.groups * 4)) : 0;
     int first, S, cps;
     nd_plan_split(ntiles, KB, slots, cap, &first, &S, &cps);
     p.split_first = first;
@@ -387,13 +471,14 @@ int nd_launch_conv_w1d(const ConvDesc &d, hipStream_t stream) {
     p.nitems = (int)(first + (ntiles - first) * S);
     p.part = (f32x4 *)d.part;
     const long grid = p.nitems < slots ? p.nitems : slots;
-    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(64 * kW1dWM * kW1dWN), lds, stream, p);
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(sh.threads), lds, stream, p);
     if (first < ntiles) {
-        // the finish kernel works in pixels: a tile of n pairs is 2n consecutive compact pixels
+        // the finish kernel works in pixel slots: a tile of n groups is T*n consecutive slots of rows T*Wg slots wide
+        // (slots past the real row width are skipped: ConvParams::wpx)
         ConvParams f = p;
-        f.Wv = Wpx;
-        f.PV = Hv * Wpx;
-        ND_TRY(nd_launch_split_finish(f, (int)(ntiles - first), kW1dMblk, 2 * kW1dPairs, 0, ND_F32, stream));
+        f.Wv = T * Wg;
+        f.PV = Hv * T * Wg;
+        ND_TRY(nd_launch_split_finish(f, (int)(ntiles - first), sh.mblk, T * sh.groups, 0, ND_F32, stream));
     }
     ND_HIP(hipGetLastError());
     return ND_OK;

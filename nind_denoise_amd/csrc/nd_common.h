@@ -82,10 +82,11 @@ size_t nd_wino_scratch_bytes(int T, const QpBuf &in, int cin, int cout);
 int nd_launch_conv_wino(int T, const ConvDesc &d, void *scratch, size_t scratch_bytes, hipStream_t s);
 int nd_conv_winograd_enabled();
 // 1-D Winograd F(2,3) along x inside the implicit-GEMM kernel (conv_w1d.hip): fp32 inference form of the narrow 3x3 layers
-size_t nd_w1d_packed_floats(int cin, int cout);
-int nd_w1d_pack(int kind, int cin, int cout, const float *w, const float *bias, float *packed);
-bool nd_w1d_applicable(const QpBuf &in);
-int nd_launch_conv_w1d(const ConvDesc &d, hipStream_t stream);
+// (T = 2: F(2,3), 2/3 of the MFMAs;  T = 4: F(4,3), 1/2)
+size_t nd_w1d_packed_floats(int T, int cin, int cout);
+int nd_w1d_pack(int T, int kind, int cin, int cout, const float *w, const float *bias, float *packed);
+bool nd_w1d_fits(int T, const QpBuf &in);
+int nd_launch_conv_w1d(int T, const ConvDesc &d, hipStream_t stream);
 const char *nd_conv_variant_label(int v);
 
 // packed size helpers (host)

@@ -42,7 +42,8 @@ extern "C" int nd_utnet_pack_weights(int funit, int dtype, const float *const *t
         } else {
             nd_pack_layer(l.kind, ci, co, dtype, tensors[wi], tensors[bi], blob + bl.off[i]);
             if (bl.woff[i]) ND_TRY(nd_wino_pack(kWinoTile, l.kind, ci, co, tensors[wi], tensors[bi], blob + bl.woff[i]));
-            if (bl.w1off[i]) ND_TRY(nd_w1d_pack(l.kind, ci, co, tensors[wi], tensors[bi], blob + bl.w1off[i]));
+            if (bl.w1off[i]) ND_TRY(nd_w1d_pack(kW1dTile, l.kind, ci, co, tensors[wi], tensors[bi], blob + bl.w1off[i]));
+            if (bl.w1off2[i]) ND_TRY(nd_w1d_pack(2, l.kind, ci, co, tensors[wi], tensors[bi], blob + bl.w1off2[i]));
         }
         if (l.prelu >= 0) {
             // activation module sits right after the layer in its Sequential: "<seq>.<k+1>.weight"
@@ -290,24 +291,25 @@ extern "C" int nd_layer_forward(int kind, int act, float slope, int dtype, const
 }
 
 // Winograd form of a 3x3 layer (tile = 2 | 4): same interface as nd_layer_forward with a blob from nd_winograd_pack
-// (tile = 1: the 1-D F(2,3) form fused into the implicit-GEMM kernel, conv_w1d.hip)
+// (tile = 1 | 3: the 1-D F(2,3) | F(4,3) form fused into the implicit-GEMM kernel, conv_w1d.hip)
+static bool wino_tile_ok(int tile) { return tile >= 1 && tile <= 4; }
 extern "C" size_t nd_winograd_packed_bytes(int tile, int cin, int cout) {
-    if ((tile != 1 && tile != 2 && tile != 4) || cin <= 0 || cout <= 0) return 0;
-    return (tile == 1 ? nd_w1d_packed_floats(cin, cout) : nd_wino_packed_floats(tile, cin, cout)) * sizeof(float);
+    if (!wino_tile_ok(tile) || cin <= 0 || cout <= 0) return 0;
+    return ((tile & 1) ? nd_w1d_packed_floats(tile + 1, cin, cout) : nd_wino_packed_floats(tile, cin, cout)) * sizeof(float);
 }
 extern "C" int nd_winograd_pack(int tile, int kind, int cin, int cout, const float *w, const float *bias, void *packed,
                                 size_t packed_bytes) {
     const size_t need = nd_winograd_packed_bytes(tile, cin, cout);
     if (!need) ND_FAIL(ND_EINVAL, "nd_winograd_pack: bad shape");
     if (!packed || packed_bytes < need) ND_FAIL(ND_ENOMEM, "nd_winograd_pack: %zu B given, %zu B needed", packed_bytes, need);
-    if (tile == 1) return nd_w1d_pack(kind, cin, cout, w, bias, (float *)packed);
+    if (tile & 1) return nd_w1d_pack(tile + 1, kind, cin, cout, w, bias, (float *)packed);
     return nd_wino_pack(tile, kind, cin, cout, w, bias, (float *)packed);
 }
 extern "C" size_t nd_layer_winograd_workspace_bytes(int tile, int kind, int batch, int cin, int cout, int h, int w) {
-    if ((tile != 1 && tile != 2 && tile != 4) || (kind != ND_CONV3 && kind != ND_CONVT3)) return 0;
+    if (!wino_tile_ok(tile) || (kind != ND_CONV3 && kind != ND_CONVT3)) return 0;
     const size_t base = nd_layer_workspace_bytes(kind, batch, cin, cout, h, w, ND_F32);
     if (!base) return 0;
-    if (tile == 1) return base;
+    if (tile & 1) return base;
     const LayerPlan pl = layer_plan(kind, batch, cin, cout, h, w, nullptr, ND_F32);
     return base + nd_wino_scratch_bytes(tile, pl.in, cin, cout);
 }
@@ -335,9 +337,9 @@ extern "C" int nd_layer_forward_winograd(int tile, int kind, int act, float slop
     d.variant = -1;
     d.part = pl.split;
     d.part_bytes = kSplitScratchBytes;
-    if (tile == 1) {
-        d.bias = d.wpk + (size_t)nd_mtiles(ND_CONV3, cout) * nd_kblocks(cin) * 12 * 256;
-        ND_TRY(nd_launch_conv_w1d(d, s));
+    if (tile & 1) {
+        d.bias = d.wpk + (size_t)nd_mtiles(ND_CONV3, cout) * nd_kblocks(cin) * 3 * (tile + 3) * 256;
+        ND_TRY(nd_launch_conv_w1d(tile + 1, d, s));
     } else {
         ND_TRY(nd_launch_conv_wino(tile, d, (char *)ws + pl.bytes, ws_bytes - pl.bytes, s));
     }
@@ -458,7 +460,7 @@ extern "C" int nd_winograd_bench(int tile, int kind, int batch, int cin, int cou
                                  size_t ws_bytes, void *stream, float *mean_ms) {
     const size_t need = nd_layer_winograd_workspace_bytes(tile, kind, batch, cin, cout, h, w);
     if (!need) ND_FAIL(ND_EINVAL, "nd_winograd_bench: bad shape / kind / tile");
-    const size_t wfloats = tile == 1 ? nd_w1d_packed_floats(cin, cout) : nd_wino_packed_floats(tile, cin, cout);
+    const size_t wfloats = (tile & 1) ? nd_w1d_packed_floats(tile + 1, cin, cout) : nd_wino_packed_floats(tile, cin, cout);
     const size_t total = ((need + 255) & ~(size_t)255) + wfloats * 4;
     if (!ws || ws_bytes < total) ND_FAIL(ND_ENOMEM, "nd_winograd_bench: workspace %zu B given, %zu B needed", ws_bytes, total);
     hipStream_t s = (hipStream_t)stream;
@@ -483,8 +485,8 @@ extern "C" int nd_winograd_bench(int tile, int kind, int batch, int cin, int cou
     d.part_bytes = kSplitScratchBytes;
     void *scratch = (char *)ws + pl.bytes;
     const size_t scratch_bytes = need - pl.bytes;
-    if (tile == 1) d.bias = d.wpk + (size_t)nd_mtiles(ND_CONV3, cout) * nd_kblocks(cin) * 12 * 256;
-    auto run = [&]() { return tile == 1 ? nd_launch_conv_w1d(d, s) : nd_launch_conv_wino(tile, d, scratch, scratch_bytes, s); };
+    if (tile & 1) d.bias = d.wpk + (size_t)nd_mtiles(ND_CONV3, cout) * nd_kblocks(cin) * 3 * (tile + 3) * 256;
+    auto run = [&]() { return (tile & 1) ? nd_launch_conv_w1d(tile + 1, d, s) : nd_launch_conv_wino(tile, d, scratch, scratch_bytes, s); };
     ND_TRY(run());
     hipEvent_t e0, e1;
     ND_HIP(hipEventCreate(&e0));

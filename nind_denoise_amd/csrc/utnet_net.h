@@ -70,21 +70,24 @@ int tensor_index(const std::string &name) {
 inline int lcin(const LayerSpec &l, int f) { return l.cin_mul ? l.cin_mul * f : 3; }
 inline int lcout(const LayerSpec &l, int f) { return l.cout_mul ? l.cout_mul * f : 3; }
 
-// Layers that run in Winograd F(4x4, 3x3) form on the fp32 inference path (winograd.hip): measured on the UtNet(64) shapes at
-// 256 tiles per launch it wins from 128 -> 128 channels up (1.26x there, 2.2 - 2.6x on the 512 / 1024-channel layers) and ties or
-// loses below (64 -> 128: 0.93x, 128 -> 64: 0.99x, 64 -> 64: 0.8x), where its transform passes cost more HBM time than the MFMAs saved
+// fp32 inference form of the 3x3 layers, chosen from measurements on the UtNet(64) shapes at 256 tiles per launch:
+//   Cin * Cout >= 128 * 256 : three-pass Winograd F(4x4, 3x3) (winograd.hip): 1.65x (128 -> 256) ... 2.6x (1024 -> 512) the direct kernel
+//   below                   : 1-D Winograd F(4, 3) along x inside the implicit-GEMM kernel (conv_w1d.hip): 1.43 - 1.5x the direct
+//                             kernel; the three-pass form is HBM-bound on its transform passes there (64 -> 64: 0.87x, 128 -> 128: 1.4x)
 constexpr int kWinoTile = 4;
+constexpr int kW1dTile = 4;
 constexpr int kWinoChunk = 64;   // images per Winograd pass (bounds the V / M scratch; the rate is flat from 32 images up)
 inline bool wino_layer(const LayerSpec &l, int f, int dt) {
     return dt == ND_F32 && (l.kind == ND_CONV3 || l.kind == ND_CONVT3) && l.cin_mul * f >= 128 && l.cout_mul * f >= 128 &&
-           (l.cin_mul * f) % 16 == 0;
+           (long)l.cin_mul * f * l.cout_mul * f >= 128L * 256 && (l.cin_mul * f) % 16 == 0;
 }
 
 // float offsets of every layer inside the packed blob
 struct BlobLayout {
     size_t off[kNumLayers];
     size_t woff[kNumLayers];   // Winograd F(4x4,3x3) form of the layer (0: none)
-    size_t w1off[kNumLayers];  // 1-D F(2,3) form fused into the implicit-GEMM kernel (conv_w1d.hip): the other fp32 3x3 layers
+    size_t w1off[kNumLayers];  // 1-D F(4,3) form fused into the implicit-GEMM kernel (conv_w1d.hip): the other fp32 3x3 layers
+    size_t w1off2[kNumLayers]; // ... and its F(2,3) form, for rows whose stage images do not fit the LDS with 18 weight planes
     size_t total;
 };
 BlobLayout blob_layout(int f, int dt, bool with_wino = true) {
@@ -104,11 +107,13 @@ BlobLayout blob_layout(int f, int dt, bool with_wino = true) {
             b.woff[i] = o;
             o += (nd_wino_packed_floats(kWinoTile, lcin(kLayers[i], f), lcout(kLayers[i], f)) + 63) / 64 * 64;
         }
-        b.w1off[i] = 0;
+        b.w1off[i] = b.w1off2[i] = 0;
         const LayerSpec &l = kLayers[i];
         if (with_wino && dt == ND_F32 && (l.kind == ND_CONV3 || l.kind == ND_CONVT3) && !b.woff[i]) {
             b.w1off[i] = o;
-            o += (nd_w1d_packed_floats(lcin(l, f), lcout(l, f)) + 63) / 64 * 64;
+            o += (nd_w1d_packed_floats(kW1dTile, lcin(l, f), lcout(l, f)) + 63) / 64 * 64;
+            b.w1off2[i] = o;
+            o += (nd_w1d_packed_floats(2, lcin(l, f), lcout(l, f)) + 63) / 64 * 64;
         }
     }
     b.total = o;
@@ -263,12 +268,15 @@ int run_stack(int f, int act, int dt, const float *blob, const Plan &pl, hipStre
         d.variant = -1;
         d.part = pl.split;
         d.part_bytes = kSplitScratchBytes;
-        if (!pre && bl.w1off[st.layer] && nd_conv_winograd_enabled() && nd_w1d_applicable(d.in)) {
-            // narrow layer: 1-D F(2,3) along x inside the implicit-GEMM kernel (2/3 of the MFMAs)
-            d.wpk = blob + bl.w1off[st.layer];
-            d.bias = d.wpk + (size_t)nd_mtiles(ND_CONV3, d.cout) * nd_kblocks(d.cin) * 12 * 256;
-            ND_TRY(nd_launch_conv_w1d(d, s));
-            continue;
+        if (!pre && bl.w1off[st.layer] && nd_conv_winograd_enabled()) {
+            // narrow layer: 1-D Winograd along x inside the implicit-GEMM kernel; F(4,3), or F(2,3) on rows too wide for it
+            const int T = nd_w1d_fits(kW1dTile, d.in) ? kW1dTile : (nd_w1d_fits(2, d.in) ? 2 : 0);
+            if (T) {
+                d.wpk = blob + (T == kW1dTile ? bl.w1off[st.layer] : bl.w1off2[st.layer]);
+                d.bias = d.wpk + (size_t)nd_mtiles(ND_CONV3, d.cout) * nd_kblocks(d.cin) * 3 * (T + 2) * 256;
+                ND_TRY(nd_launch_conv_w1d(T, d, s));
+                continue;
+            }
         }
         if (!pre && bl.woff[st.layer] && nd_conv_winograd_enabled()) {
             // Winograd form, kWinoChunk images per pass (views of the same buffers)

@@ -191,19 +191,18 @@ WINO_CASES = [
 
 
 @pytest.mark.parametrize("case", WINO_CASES, ids=lambda c: "-".join(str(v) for v in c))
-@pytest.mark.parametrize("tile", [1, 2, 4])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
 def test_layer_winograd(dev, case, tile):
     """Winograd F(t x t, 3 x 3) form of a 3x3 layer (csrc/winograd.hip: input transform, 16 / 36 batched GEMMs in one launch,
     output transform) against torch and against the direct kernel."""
     kind, B, cin, cout, H, W, act = case
-    if tile == 1 and W % 2:      # tile 1 = the 1-D F(2,3) form fused into the implicit-GEMM kernel: even rows only
-        W += 1
+    # tile 1 | 3 = the 1-D F(2,3) | F(4,3) form fused into the implicit-GEMM kernel; 2 | 4 = the three-pass F(2x2) | F(4x4) form
     x = rnd((B, cin, H, W), 1)
     bound = 1.0 / np.sqrt(cin * 9)
     wshape = (cout, cin, 3, 3) if kind == "conv3" else (cin, cout, 3, 3)
     w = rnd(wshape, 2, bound * 1.7)
     b = rnd((cout,), 3, 0.2)
-    if tile != 1 and cin % 16:
+    if tile % 2 == 0 and cin % 16:
         pytest.skip("the three-pass form needs Cin % 16 == 0")
     lib = _lib.load()
     k = _lib.KIND[kind]
@@ -224,8 +223,8 @@ def test_layer_winograd(dev, case, tile):
     err = assert_close(y, ref, f"winograd F({tile},3) {case}")
     direct = layer_forward(dev, kind, x, w, b, act, 0.13)
     scale = max(1.0, ref.abs().max().item())
-    assert (y - direct).abs().max().item() <= (2e-5 if tile == 2 else 1e-4) * scale
-    print(f"winograd F({tile},3) {case}: max abs err {err:.2e}")
+    assert (y - direct).abs().max().item() <= (2e-5 if tile <= 2 else 1e-4) * scale
+    print(f"winograd tile code {tile} {case}: max abs err {err:.2e}")
 
 
 def test_layer_asymmetric_identity(dev):
