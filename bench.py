@@ -134,7 +134,7 @@ def executed_flop(name, flop, cs, batch, funit, dtype):
 
 
 def pmc_traffic(cs, batch, funit):
-    """HBM bytes per launch of the dominant kernel (the fp32 3x3 conv_qp variants) from the committed rocprofv3 PMC passes
+    """HBM bytes per launch of the dominant kernel (conv_w1d, the fused 1-D Winograd 3x3 kernel) from the committed rocprofv3 PMC passes
     (FETCH_SIZE and WRITE_SIZE collected in separate runs, gfx950 read correction applied -- profiles/*_pmc_summary.json).
     Counters cannot be read inside the timed run, so this is null unless a profile of the same configuration exists."""
     import glob
@@ -148,8 +148,10 @@ def pmc_traffic(cs, batch, funit):
         if (c.get("cs"), c.get("tiles_per_launch"), c.get("funit")) != (cs, batch, funit):
             continue
         rd = wr = n = 0
-        for name, v in d.get("kernels", {}).items():   # every fp32 3x3 variant of the dominant kernel, dispatch weighted
-            if name.startswith("conv_qp<0,") and ", 9, 1, false" in name and "hbm_read_bytes_mean" in v:
+        dominant = [n for n in d.get("kernels", {}) if n.startswith("conv_w1d<")] or \
+                   [n for n in d.get("kernels", {}) if n.startswith("conv_qp<0,") and ", 9, 1, false" in n]
+        for name, v in d.get("kernels", {}).items():   # the dominant kernel (fused 1-D Winograd 3x3; else the direct 3x3 variants)
+            if name in dominant and "hbm_read_bytes_mean" in v:
                 k = v["FETCH_SIZE"]["dispatches"]
                 rd += v["hbm_read_bytes_mean"] * k
                 wr += v["hbm_write_bytes_mean"] * k
@@ -310,7 +312,7 @@ def main():
                 "mfma_executed_tflops": round(exe_flop / (conv_ms * 1e-3) / 1e12, 3),
                 "mfma_executed_frac": round(exe_flop / (conv_ms * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS[args.dtype], 4),
                 "traffic": (pmc_traffic(cs, b, args.funit) or {}).get("bytes_per_launch") if args.dtype == "f32" else None,
-                "traffic_unit": "HBM bytes per launch of the 3x3 conv_qp variant (PMC FETCH_SIZE*2 + WRITE_SIZE)",
+                "traffic_unit": "HBM bytes per launch of the dominant kernel, conv_w1d (PMC FETCH_SIZE*2 + WRITE_SIZE)",
                 "traffic_detail": pmc_traffic(cs, b, args.funit) if args.dtype == "f32" else None,
                 "launches": len([s for s in steps if s["conv"]]),
                 "avg_launch_ms": round(conv_ms / max(1, len([s for s in steps if s["conv"]])), 4),

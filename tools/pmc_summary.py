@@ -17,7 +17,7 @@ def main():
     for d in sys.argv[1:]:
         for f in glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True):
             for r in csv.DictReader(open(f)):
-                name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")
+                name = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")).replace("void ", "")
                 out[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
     res = {}
     for k, cs in sorted(out.items()):
