@@ -232,7 +232,8 @@ const char *nd_conv_variant_name(int variant);
 int nd_conv_split_enable(int on);
 
 /* Winograd F(4x4, 3x3) form of the >= 128-channel 3x3 layers on the fp32 inference path (on by default; ~1e-5 relative
- * re-association error per layer, 1.4x on the UtNet(64) conv stack).  Returns the previous setting. */
+ * re-association error per layer) and 1-D F(4,3) inside the implicit-GEMM kernel on the narrower ones: 1.67x on the UtNet(64) conv
+ * stack.  Returns the previous setting. */
 int nd_conv_winograd_enable(int on);
 
 #ifdef __cplusplus
