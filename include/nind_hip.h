@@ -204,8 +204,10 @@ size_t nd_ssim_loss_workspace_bytes(int n, int c, int h, int w);
 int nd_ssim_loss_grad(const float *x, const float *y, int n, int c, int h, int w, int multiscale, float weight,
                       float *loss_acc, float *gx, int accumulate, void *workspace, size_t workspace_bytes, void *stream);
 
-/* ---- Winograd F(t x t, 3 x 3), t = 2 | 4: fp32 inference form of the wide 3x3 layers (same math as nd_layer_forward on a
- * CONV3 / CONVT3 layer, re-associated: results agree to ~1e-6 (t = 2) / ~1e-5 (t = 4) relative).  Cin % 16 == 0. */
+/* ---- Winograd forms of a 3x3 layer, fp32 inference (same math as nd_layer_forward on a CONV3 / CONVT3 layer, re-associated).
+ * tile = 2 | 4: three-pass F(tile x tile, 3 x 3) (input transform, one launch of (tile+2)^2 GEMMs, output transform;
+ *               Cin % 16 == 0; agrees with the direct kernel to ~1e-6 / ~1e-5 relative);
+ * tile = 1 | 3: 1-D F(2,3) | F(4,3) along x inside the implicit-GEMM kernel (~1e-6 / ~5e-6). */
 size_t nd_winograd_packed_bytes(int tile, int cin, int cout);
 int nd_winograd_pack(int tile, int kind, int cin, int cout, const float *w, const float *bias, void *packed,
                      size_t packed_bytes);
