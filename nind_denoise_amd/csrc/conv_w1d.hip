@@ -120,12 +120,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_w1d(ConvParams p) {
             ok = r < p.PV;
             r = ok ? r : p.PV - 1;
         } else {
-            const long g = (long)nb * NBLK + l;
-            const long tot = (long)p.nimg * p.PV;
+            const unsigned g = (unsigned)nb * NBLK + l;      // < 2^31: the launcher checks the pixel count
+            const unsigned tot = (unsigned)p.nimg * p.PV;
             ok = g < tot;
-            const long gc = ok ? g : tot - 1;
-            img = (int)(gc / p.PV);
-            r = (int)(gc - (long)img * p.PV);
+            const unsigned gc = ok ? g : tot - 1;
+            img = (int)(gc / (unsigned)p.PV);
+            r = (int)(gc - (unsigned)img * p.PV);
         }
         return ok;
     };
@@ -273,9 +273,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_w1d(ConvParams p) {
         fill_next();
         const char *sb = smem + c_stage * stageB;
         const char *bp = sb + bOff;
-        f32x4 d[2][NP];
+        f32x4 d[2][NP], a[2][MR];
 #pragma unroll
         for (int i = 0; i < NP; ++i) d[0][i] = *(const f32x4 *)(bp + i * 16);
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) a[0][mr] = *(const f32x4 *)(sb + aOff + (mr * TAPS) * 1024);
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             if (ky + 1 < 3) {
@@ -292,14 +294,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_w1d(ConvParams p) {
             W1<T>::in(d[ky & 1], v);
 #pragma unroll
             for (int xi = 0; xi < NP; ++xi) {
-                f32x4 a[MR];
+                const int st = ky * NP + xi;
+                if (st + 1 < TAPS) {   // weight fragments of the next (ky, position) ahead of this one's MFMAs
 #pragma unroll
-                for (int mr = 0; mr < MR; ++mr) a[mr] = *(const f32x4 *)(sb + aOff + (mr * TAPS + ky * NP + xi) * 1024);
+                    for (int mr = 0; mr < MR; ++mr) a[(st + 1) & 1][mr] = *(const f32x4 *)(sb + aOff + (mr * TAPS + st + 1) * 1024);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int mr = 0; mr < MR; ++mr)
-                        acc[xi][mr] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mr][q], v[xi][q], acc[xi][mr], 0, 0, 0);
+                        acc[xi][mr] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st & 1][mr][q], v[xi][q], acc[xi][mr], 0, 0, 0);
             }
         }
         c_stage = (c_stage + 1 == NSTAGE) ? 0 : c_stage + 1;
