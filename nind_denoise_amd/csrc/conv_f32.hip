@@ -108,7 +108,10 @@ __global__ __launch_bounds__(256) void k_split_finish(ConvParams p, int mblk, in
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         for (int ks = 0; ks < p.S; ++ks) acc += p.part[((size_t)(t * p.S + ks) * nq + quad) * nblk + l];
         acc += bv;
-        if (p.pre) p.pre[(long)(m4 >> 2) * p.pre_plane + (long)bi * p.PV + r] = acc;
+        if (p.pre) {
+            const long pr = p.wpx ? ((long)bi * p.Hv + r / p.Wv) * p.wpx + (r - (r / p.Wv) * p.Wv) : (long)bi * p.PV + r;
+            if (!p.wpx || r - (r / p.Wv) * p.Wv < p.wpx) p.pre[(long)(m4 >> 2) * p.pre_plane + pr] = acc;
+        }
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = p.act <= ND_ACT_PRELU ? (acc[e] > 0.f ? acc[e] : acc[e] * slope) : apply_act(acc[e], p.act, slope);

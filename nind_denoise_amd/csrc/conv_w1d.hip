@@ -235,10 +235,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_w1d(ConvParams p) {
                 combine(mr, g, yy);
                 if (valid && m4 < p.M) {
                     f32x4 *dst = p.out + (long)(p.out_plane0 + (m4 >> 2)) * p.out_plane + pix;
+                    // training forward: keep acc + bias for the activation's backward pass (compact [C/4][B][Hv][wpx] planes)
+                    f32x4 *pre = p.pre ? p.pre + (long)(m4 >> 2) * p.pre_plane + ((long)bi * p.Hv + y) * p.wpx + T * xp : nullptr;
 #pragma unroll
                     for (int i = 0; i < T; ++i) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) yy[i][e] = apply_act(yy[i][e] + (h ? b8[4 + e] : b8[e]), p.act, slope);
+                        for (int e = 0; e < 4; ++e) yy[i][e] += h ? b8[4 + e] : b8[e];
+                        if (pre && i < left) pre[i] = yy[i];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) yy[i][e] = apply_act(yy[i][e], p.act, slope);
                         if (i < left) dst[i] = yy[i];
                     }
                 }
@@ -398,11 +403,11 @@ bool nd_w1d_fits(int T, const QpBuf &in) {
 int nd_launch_conv_w1d(int T, const ConvDesc &d, hipStream_t stream) {
     if (T != 2 && T != 4) ND_FAIL(ND_EINVAL, "w1d: group size must be 2 or 4");
     if ((d.kind != ND_CONV3 && d.kind != ND_CONVT3) || d.in.dt != ND_F32 || d.out.dt != ND_F32) ND_FAIL(ND_EINVAL, "w1d: fp32 3x3 layers only");
-    if (d.pre || d.in_plane0) ND_FAIL(ND_EINVAL, "w1d: inference only");
+    if (d.pre && d.pre_plane < (long)d.in.B * (d.in.Hb - 2) * (d.in.Wb - 2)) ND_FAIL(ND_EINVAL, "w1d: pre-activation planes too small");
     if (d.cout % 4) ND_FAIL(ND_EINVAL, "w1d: cout must be a multiple of 4");
     const W1Shape &sh = shape_of(T);
     const int KB = nd_kblocks(d.cin);
-    if (d.in.planes < 2 * KB) ND_FAIL(ND_EINVAL, "w1d: input buffer has %d planes, needs %d", d.in.planes, 2 * KB);
+    if (d.in.planes < d.in_plane0 + 2 * KB) ND_FAIL(ND_EINVAL, "w1d: input buffer has %d planes, needs %d", d.in.planes, d.in_plane0 + 2 * KB);
     const int Hv = d.in.Hb - 2, Wpx = d.in.Wb - 2, Wg = (Wpx + T - 1) / T;
     if (Hv < 1 || Wpx < 1) ND_FAIL(ND_EINVAL, "w1d: input smaller than the kernel");
     if (d.out.Hb != Hv + 2 * d.out.pad || d.out.Wb != Wpx + 2 * d.out.pad || d.out.B != d.in.B) ND_FAIL(ND_EINVAL, "w1d: destination does not fit the result");
@@ -429,7 +434,7 @@ int nd_launch_conv_w1d(int T, const ConvDesc &d, hipStream_t stream) {
     }
 
     ConvParams p = {};
-    p.in = (const f32x4 *)d.in.base;
+    p.in = (const f32x4 *)d.in.base + (long)d.in_plane0 * d.in.np();
     p.wpk = d.wpk;
     p.bias = d.bias;
     p.out = (f32x4 *)d.out.base;
@@ -445,7 +450,8 @@ int nd_launch_conv_w1d(int T, const ConvDesc &d, hipStream_t stream) {
     p.G = G;
     p.stride = 1;
     p.ioff = 0;
-    p.pre = nullptr;
+    p.pre = (f32x4 *)d.pre;
+    p.pre_plane = d.pre_plane;
     p.KB = KB;
     p.M = d.cout;
     p.cout = d.cout;

@@ -90,7 +90,15 @@ struct BlobLayout {
     size_t w1off2[kNumLayers]; // ... and its F(2,3) form, for rows whose stage images do not fit the LDS with 18 weight planes
     size_t total;
 };
-BlobLayout blob_layout(int f, int dt, bool with_wino = true) {
+// train: the layout of the training step's forward blob -- every 3x3 region can hold either the direct or the fused 1-D
+// Winograd packing (the step picks per layer), no separate Winograd regions
+inline size_t layer_floats(const LayerSpec &l, int f, int dt, bool train) {
+    const size_t direct = nd_packed_floats(l.kind, lcin(l, f), lcout(l, f), dt);
+    if (!train || dt != ND_F32 || (l.kind != ND_CONV3 && l.kind != ND_CONVT3)) return direct;
+    const size_t w1 = nd_w1d_packed_floats(kW1dTile, lcin(l, f), lcout(l, f));
+    return w1 > direct ? w1 : direct;
+}
+BlobLayout blob_layout(int f, int dt, bool with_wino = true, bool train = false) {
     BlobLayout b;
     size_t o = kHeaderFloats;
     for (int i = 0; i < kNumLayers; ++i) {
@@ -99,7 +107,7 @@ BlobLayout blob_layout(int f, int dt, bool with_wino = true) {
         if (i == kNumLayers - 1)
             o += ((size_t)3 * lcin(l, f) + 3 + 3) / 4 * 4;  // raw [3][cin] + bias[3] for the VALU 1x1 kernel
         else
-            o += nd_packed_floats(l.kind, lcin(l, f), lcout(l, f), dt);
+            o += layer_floats(l, f, dt, train);
     }
     for (int i = 0; i < kNumLayers; ++i) {
         b.woff[i] = 0;
@@ -235,9 +243,10 @@ Plan make_plan(int f, int ch_, int cw_, int cap, int nimg, char *base, int dt) {
 
 // ev (optional): kNumSteps+1 events, ev[i] recorded before step i, ev[kNumSteps] after the last one
 // pre (optional, training): kNumSlopes compact buffers that receive acc + bias of every activated layer
+// train_w1 (training forward, with pre): per layer, 1 = the layer's blob region holds the fused 1-D Winograd packing
 int run_stack(int f, int act, int dt, const float *blob, const Plan &pl, hipStream_t s, hipEvent_t *ev = nullptr,
-              const QpBuf *pre = nullptr, const float *slopes = nullptr) {
-    const BlobLayout bl = blob_layout(f, dt);
+              const QpBuf *pre = nullptr, const float *slopes = nullptr, const unsigned char *train_w1 = nullptr) {
+    const BlobLayout bl = blob_layout(f, dt, pre == nullptr, pre != nullptr);
     const int cpp = nd_cpp(dt);
     int si = 0;
     for (const Step &st : kSteps) {
@@ -268,6 +277,11 @@ int run_stack(int f, int act, int dt, const float *blob, const Plan &pl, hipStre
         d.variant = -1;
         d.part = pl.split;
         d.part_bytes = kSplitScratchBytes;
+        if (pre && train_w1 && train_w1[st.layer]) {
+            d.bias = d.wpk + (size_t)nd_mtiles(ND_CONV3, d.cout) * nd_kblocks(d.cin) * 3 * (kW1dTile + 2) * 256;
+            ND_TRY(nd_launch_conv_w1d(kW1dTile, d, s));
+            continue;
+        }
         if (!pre && bl.w1off[st.layer] && nd_conv_winograd_enabled()) {
             // narrow layer: 1-D Winograd along x inside the implicit-GEMM kernel; F(4,3), or F(2,3) on rows too wide for it
             const int T = nd_w1d_fits(kW1dTile, d.in) ? kW1dTile : (nd_w1d_fits(2, d.in) ? 2 : 0);

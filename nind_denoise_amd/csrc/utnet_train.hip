@@ -13,6 +13,8 @@
 // optimizer are single flat operations.
 #include <math.h>
 
+#include <algorithm>
+
 #include "utnet_net.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -238,6 +240,40 @@ __global__ void k_pack_dev(int kind, int cin, int cout, int M, int KB, int taps,
     }
 }
 
+// the same for the fused 1-D Winograd F(4,3) form of a 3x3 layer (conv_w1d.hip: nd_w1d_pack): [mt][kb][ky*6 + xi][lane][4] + bias
+__global__ void k_pack_w1d_dev(int kind, int cin, int cout, int KB, const float *__restrict__ w, const float *__restrict__ bias,
+                               float *__restrict__ packed, long nw, int nb) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < nw) {
+        const int s = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+        long rest = idx >> 8;
+        const int plane = (int)(rest % 18);
+        rest /= 18;
+        const int kb = (int)(rest % KB), mt = (int)(rest / KB);
+        const int ky = plane / 6, xi = plane - 6 * ky;
+        const int m = 32 * mt + (lane & 31), ci = 8 * kb + 4 * (lane >> 5) + s;
+        float v = 0.f;
+        if (m < cout && ci < cin) {
+            float g[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                g[k] = kind == ND_CONV3 ? w[((long)m * cin + ci) * 9 + ky * 3 + k] : w[((long)ci * cout + m) * 9 + (8 - (ky * 3 + k))];
+            switch (xi) {
+                case 0: v = g[0] / 4.f; break;
+                case 1: v = -(g[0] + g[1] + g[2]) / 6.f; break;
+                case 2: v = -(g[0] - g[1] + g[2]) / 6.f; break;
+                case 3: v = g[0] / 24.f + g[1] / 12.f + g[2] / 6.f; break;
+                case 4: v = g[0] / 24.f - g[1] / 12.f + g[2] / 6.f; break;
+                default: v = g[2]; break;
+            }
+        }
+        packed[idx] = v;
+    } else if (idx < nw + nb) {
+        const int m = (int)(idx - nw);
+        packed[idx] = (m < cout && bias) ? bias[m] : 0.f;
+    }
+}
+
 // Adam with amsgrad, torch.optim.Adam semantics (nn_common.py:185): no weight decay
 __global__ void k_adam(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
                        float *__restrict__ vmax, long n, float lr, float b1, float b2, float eps, float bc1, float bc2,
@@ -305,7 +341,10 @@ BwdBlob bwd_blob_layout(int f) {
         b.off[i] = o;
         const LayerSpec &l = kLayers[i];
         if (i == 0 || l.kind == ND_CONV1) continue;
-        o += nd_packed_floats(transposed_kind(l.kind), lcout(l, f), lcin(l, f), ND_F32);
+        const int kt = transposed_kind(l.kind);
+        size_t n = nd_packed_floats(kt, lcout(l, f), lcin(l, f), ND_F32);
+        if (kt == ND_CONV3 || kt == ND_CONVT3) n = std::max(n, nd_w1d_packed_floats(kW1dTile, lcout(l, f), lcin(l, f)));   // either packing
+        o += n;
     }
     b.total = o;
     return b;
@@ -451,7 +490,7 @@ extern "C" int nd_utnet_param_range(int funit, int tensor_idx, size_t *offset, s
 }
 extern "C" size_t nd_utnet_train_blob_bytes(int funit) {
     if (funit < 8 || funit % 8) return 0;
-    return (blob_layout(funit, ND_F32, false).total + bwd_blob_layout(funit).total) * sizeof(float);
+    return (blob_layout(funit, ND_F32, false, true).total + bwd_blob_layout(funit).total) * sizeof(float);
 }
 extern "C" size_t nd_utnet_train_workspace_bytes(int funit, int cs, int batch) {
     if (check_train(funit, cs, batch) != ND_OK) return 0;
@@ -483,7 +522,19 @@ extern "C" int nd_utnet_train_step(int funit, const float *params, float *grads,
     hipStream_t s = (hipStream_t)stream;
     const int f = funit, B = batch;
     const ParamLayout pl = param_layout(f);
-    const BlobLayout bl = blob_layout(f, ND_F32, false);   // training keeps the direct form (pre-activation copies)
+    const BlobLayout bl = blob_layout(f, ND_F32, false, true);
+    // 3x3 layers whose rows fit its LDS images run the fused 1-D Winograd kernel, forward and data gradient (else the direct one)
+    static_assert(kW1dTile == 4, "k_pack_w1d_dev packs the F(4,3) planes");
+    unsigned char fwd_w1[kNumLayers] = {}, bwd_w1[kNumLayers] = {};
+    for (const Step &st : kSteps) {
+        if (st.layer < 0) continue;
+        const LayerSpec &l = kLayers[st.layer];
+        if (l.kind != ND_CONV3 && l.kind != ND_CONVT3) continue;
+        if (nd_conv_winograd_enabled()) {
+            fwd_w1[st.layer] = nd_w1d_fits(kW1dTile, t.fwd.buf[st.src]);
+            bwd_w1[st.layer] = st.layer > 0 && nd_w1d_fits(kW1dTile, t.g[st.dst]);
+        }
+    }
     const BwdBlob bb = bwd_blob_layout(f);
     float *fblob = (float *)blobs;
     float *bblob = fblob + bl.total;
@@ -504,17 +555,29 @@ extern "C" int nd_utnet_train_step(int funit, const float *params, float *grads,
         }
         {
             const int MT = nd_mtiles(l.kind, co), KB = nd_kblocks(ci), taps = nd_taps(l.kind);
-            const long nw = (long)MT * KB * taps * 256;
             const int M = l.kind == ND_CONVT2S2 ? 4 * co : co;
-            hipLaunchKernelGGL(k_pack_dev, dim3((unsigned)((nw + MT * 32 + 255) / 256)), dim3(256), 0, s, l.kind, ci, co, M, KB,
-                               taps, w, b, fblob + bl.off[i], nw, MT * 32);
+            if (fwd_w1[i]) {
+                const long nw = (long)MT * KB * 18 * 256;
+                hipLaunchKernelGGL(k_pack_w1d_dev, dim3((unsigned)((nw + MT * 32 + 255) / 256)), dim3(256), 0, s, l.kind, ci, co, KB, w, b,
+                                   fblob + bl.off[i], nw, MT * 32);
+            } else {
+                const long nw = (long)MT * KB * taps * 256;
+                hipLaunchKernelGGL(k_pack_dev, dim3((unsigned)((nw + MT * 32 + 255) / 256)), dim3(256), 0, s, l.kind, ci, co, M, KB,
+                                   taps, w, b, fblob + bl.off[i], nw, MT * 32);
+            }
         }
         if (i > 0) {   // transposed role: cin' = co, cout' = ci, no bias
             const int kt = transposed_kind(l.kind);
             const int MT = nd_mtiles(kt, ci), KB = nd_kblocks(co), taps = nd_taps(kt);
-            const long nw = (long)MT * KB * taps * 256;
-            hipLaunchKernelGGL(k_pack_dev, dim3((unsigned)((nw + MT * 32 + 255) / 256)), dim3(256), 0, s, kt, co, ci, ci, KB, taps,
-                               w, (const float *)nullptr, bblob + bb.off[i], nw, MT * 32);
+            if (bwd_w1[i]) {
+                const long nw = (long)MT * KB * 18 * 256;
+                hipLaunchKernelGGL(k_pack_w1d_dev, dim3((unsigned)((nw + MT * 32 + 255) / 256)), dim3(256), 0, s, kt, co, ci, KB, w,
+                                   (const float *)nullptr, bblob + bb.off[i], nw, MT * 32);
+            } else {
+                const long nw = (long)MT * KB * taps * 256;
+                hipLaunchKernelGGL(k_pack_dev, dim3((unsigned)((nw + MT * 32 + 255) / 256)), dim3(256), 0, s, kt, co, ci, ci, KB, taps,
+                                   w, (const float *)nullptr, bblob + bb.off[i], nw, MT * 32);
+            }
         }
     }
     ND_HIP(hipGetLastError());
@@ -524,7 +587,7 @@ extern "C" int nd_utnet_train_step(int funit, const float *params, float *grads,
 
     // ---- 2. forward (training mode: pre-activations kept)
     ND_TRY(nd_launch_reflect_pack(x, B, cs, cs, t.fwd.buf[X0], s));
-    ND_TRY(run_stack(f, ND_ACT_PRELU, ND_F32, fblob, t.fwd, s, nullptr, t.pre));
+    ND_TRY(run_stack(f, ND_ACT_PRELU, ND_F32, fblob, t.fwd, s, nullptr, t.pre, nullptr, fwd_w1));
     const float *fw = fblob + bl.off[kNumLayers - 1];
     ND_TRY(nd_launch_final1x1(t.fwd.buf[T4B], f, fw, fw + 3 * f, 2, y_out, cs, cs, s));
 
@@ -629,7 +692,12 @@ extern "C" int nd_utnet_train_step(int funit, const float *params, float *grads,
             d.variant = -1;
             d.part = t.fwd.split;
             d.part_bytes = kSplitScratchBytes;
-            ND_TRY(nd_launch_conv(d, s));
+            if (bwd_w1[st.layer]) {
+                d.bias = d.wpk + (size_t)nd_mtiles(ND_CONV3, ci) * nd_kblocks(co) * 18 * 256;
+                ND_TRY(nd_launch_conv_w1d(kW1dTile, d, s));
+            } else {
+                ND_TRY(nd_launch_conv(d, s));
+            }
         }
     }
     return ND_OK;
