@@ -23,7 +23,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--dtype", default="f32")
-    ap.add_argument("--batch", type=int, default=160)
+    ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--width", type=int, default=6000)
     ap.add_argument("--height", type=int, default=4000)
     args = ap.parse_args()
