@@ -122,7 +122,7 @@ def main(argv=None):
                 outimg_path = outimg_path + '.tif'
             if not (os.path.isfile(outimg_path) and args.skip_existing):
                 denoise_image.denoise_file(model, inimg_path, outimg_path, args.cs, args.ucs, args.overlap,
-                                           batch=args.batch_size or 32, whole_image=args.whole_image,
+                                           batch=args.batch_size or 64, whole_image=args.whole_image,
                                            pad=128 if args.whole_image else args.pad, max_subpixels=args.max_subpixels,
                                            device=device, verbose=False)
             cur_losses = pt_helpers.get_losses(baseline_fpath, outimg_path, device=device)

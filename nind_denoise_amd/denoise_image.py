@@ -124,7 +124,7 @@ def build_parser():
     parser.add_argument('-ol', '--overlap', default=6, type=int, help='Merge crops with this much overlap (Reduces grid artifacts, may reduce sharpness between crops, costs computation time)')
     parser.add_argument('-i', '--input', default='in.jpg', type=str, help='Input image file')
     parser.add_argument('-o', '--output', type=str, help='Output file with extension (default: model_dpath/test/denoised_images/fn.tif)')
-    parser.add_argument('-b', '--batch_size', type=int, default=None, help='Tiles per launch of the conv stack (results do not depend on it; default 32)')
+    parser.add_argument('-b', '--batch_size', type=int, default=None, help='Tiles per launch of the conv stack (results do not depend on it; default 64)')
     parser.add_argument('--debug', action='store_true', help='Debug (display useful messages)')
     parser.add_argument('--exif_method', default='piexif', type=str, help='How is exif data copied over? (piexif, exiftool, noexif)')
     parser.add_argument('--g_network', '--network', '--arch', type=str, help='Generator network (typically UNet or UtNet)')
@@ -216,7 +216,7 @@ def main(argv=None):
     model.eval()
     model = model.to(device)
     start_time = time.time()
-    denoise_file(model, args.input, args.output, args.cs, args.ucs, args.overlap, batch=args.batch_size or 32,
+    denoise_file(model, args.input, args.output, args.cs, args.ucs, args.overlap, batch=args.batch_size or 64,
                  whole_image=args.whole_image, pad=args.pad, max_subpixels=args.max_subpixels, device=device)
     print(f'Denoised image written to {args.output}')
     copy_exif(args)
