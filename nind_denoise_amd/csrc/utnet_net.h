@@ -76,7 +76,8 @@ inline int lcout(const LayerSpec &l, int f) { return l.cout_mul ? l.cout_mul * f
 //                             kernel; the three-pass form is HBM-bound on its transform passes there (64 -> 64: 0.87x, 128 -> 128: 1.4x)
 constexpr int kWinoTile = 4;
 constexpr int kW1dTile = 4;
-constexpr int kWinoChunk = 64;   // images per Winograd pass (bounds the V / M scratch; the rate is flat from 32 images up)
+constexpr int kWinoChunk = 256;  // images per three-pass Winograd pass: bounds the V / M scratch (60 MB per 264-pixel tile for the
+                                 // largest layer); G24 at 256 tiles per launch: 46.1 MP/s with 64, 47.4 with 128, 47.8 with 256
 inline bool wino_layer(const LayerSpec &l, int f, int dt) {
     return dt == ND_F32 && (l.kind == ND_CONV3 || l.kind == ND_CONVT3) && l.cin_mul * f >= 128 && l.cout_mul * f >= 128 &&
            (long)l.cin_mul * f * l.cout_mul * f >= 128L * 256 && (l.cin_mul * f) % 16 == 0;
