@@ -438,6 +438,26 @@ def test_utnet_vs_oracle_other_sizes(dev):
         assert_close(net(x.to(dev)), ref, f"f16 cs{cs}")
 
 
+def test_utnet_f64_smallest_tile_and_many_tiles(dev):
+    # production width at the smallest valid tile (1x1 pixels at the bottom level: Winograd tiles mostly padding) and more tiles
+    # than one three-pass Winograd pass takes (kWinoChunk = 256): every tile must equal the same tile run alone
+    from nind_denoise_amd.networks.UtNet import UtNet
+    from oracle import networks as onet
+    sd = synth.make_utnet_state_dict(funit=64, seed=123)
+    net = UtNet()
+    net.load_state_dict(sd)
+    net = net.eval().to(dev)
+    x = torch.rand(3, 3, 104, 104, generator=torch.Generator().manual_seed(7))
+    with torch.no_grad():
+        ref = onet.utnet_forward(sd, x)
+    assert_close(net(x.to(dev)), ref, "f64 cs104")
+    xb = x.repeat(90, 1, 1, 1)[:262].to(dev)           # 262 tiles: one full pass of 256 and a tail of 6
+    yb = net(xb)
+    assert_close(yb[:3], ref, "f64 cs104, first tiles of 262")
+    assert_close(yb[-3:], net(xb[-3:]), "f64 cs104, tail tiles of 262")
+    assert (yb[255] - yb[0]).abs().max().item() < 1e-5 and (yb[258] - yb[0]).abs().max().item() < 1e-5   # 255, 258 = tile 0 again
+
+
 def test_utnet_rejects_invalid_cs_and_cpu(dev):
     from nind_denoise_amd.networks.UtNet import UtNet
     net = UtNet(funit=8).to(dev)
