@@ -89,6 +89,10 @@ int nd_utnet_pack_weights(int funit, int dtype, const float *const *tensors, int
 
 /* Workspace for one (cs, batch) geometry: activations in the quad-planar layout, zero borders included.
  * nd_utnet_workspace_init must run once on a workspace before its first forward with that geometry. */
+/* The same blob built in HBM from tensors that already live there (fp32 storage only): device-side packers; the Winograd
+ * weight transforms are evaluated in fp32 instead of double (packed values agree to ~1e-7 relative).  Stream-ordered. */
+int nd_utnet_pack_weights_device(int funit, int dtype, const float *const *dev_tensors, int n_tensors, void *packed_dev,
+                                 size_t packed_bytes, void *stream);
 size_t nd_utnet_workspace_bytes(int funit, int cs, int batch, int dtype);
 int nd_utnet_workspace_init(void *workspace, size_t workspace_bytes, int funit, int cs, int batch, int dtype,
                             void *stream);

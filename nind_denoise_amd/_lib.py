@@ -36,6 +36,7 @@ _SIGNATURES = {
     "nd_utnet_tensor_name": (c_char_p, [c_int]),
     "nd_utnet_packed_bytes": (c_size_t, [c_int, c_int]),
     "nd_utnet_pack_weights": (c_int, [c_int, c_int, POINTER(c_void_p), c_int, c_void_p, c_size_t]),
+    "nd_utnet_pack_weights_device": (c_int, [c_int, c_int, POINTER(c_void_p), c_int, c_void_p, c_size_t, c_void_p]),
     "nd_utnet_workspace_bytes": (c_size_t, [c_int] * 4),
     "nd_utnet_workspace_init": (c_int, [c_void_p, c_size_t] + [c_int] * 4 + [c_void_p]),
     "nd_utnet_workspace_bytes_hw": (c_size_t, [c_int] * 5),

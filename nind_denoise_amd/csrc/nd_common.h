@@ -106,6 +106,11 @@ static inline void nd_pack_layer_f32(int kind, int cin, int cout, const float *w
     nd_pack_layer(kind, cin, cout, ND_F32, w, bias, packed);
 }
 
+// device-side packers (pack_dev.hip): the same layouts from weights in HBM (fp32)
+int nd_pack_layer_device(int kind, int cin, int cout, const float *w, const float *bias, float *packed, hipStream_t s);
+int nd_pack_w1d_device(int T, int kind, int cin, int cout, const float *w, const float *bias, float *packed, hipStream_t s);
+int nd_pack_wino_device(int T, int kind, int cin, int cout, const float *w, const float *bias, float *packed, hipStream_t s);
+
 // ------------------------------------------------------------------ auxiliary kernels (aux_kernels.hip)
 int nd_launch_nchw_to_qp(const float *x, int C, const QpBuf &dst, int plane0, hipStream_t s);
 int nd_launch_qp_to_nchw(const QpBuf &src, int plane0, float *y, int C, hipStream_t s);

@@ -57,6 +57,48 @@ extern "C" int nd_utnet_pack_weights(int funit, int dtype, const float *const *t
     return ND_OK;
 }
 
+// Same blob from tensors that already live in HBM (fp32 storage only): device-side packers, nothing touches the host.
+extern "C" int nd_utnet_pack_weights_device(int funit, int dtype, const float *const *tensors, int n_tensors, void *packed_dev,
+                                            size_t packed_bytes, void *stream) {
+    ND_TRY(check_funit(funit, dtype));
+    if (dtype != ND_F32) ND_FAIL(ND_EINVAL, "nd_utnet_pack_weights_device: fp32 storage only (16-bit blobs are packed on the host)");
+    if (n_tensors != nd_utnet_num_tensors()) ND_FAIL(ND_EINVAL, "nd_utnet_pack_weights_device: expected %d tensors, got %d", nd_utnet_num_tensors(), n_tensors);
+    const BlobLayout bl = blob_layout(funit, dtype);
+    if (!packed_dev || packed_bytes < bl.total * sizeof(float)) ND_FAIL(ND_ENOMEM, "nd_utnet_pack_weights_device: packed buffer too small");
+    hipStream_t s = (hipStream_t)stream;
+    float *blob = (float *)packed_dev;
+    ND_HIP(hipMemsetAsync(blob, 0, bl.total * sizeof(float), s));
+    for (int i = 0; i < kNumLayers; ++i) {
+        const LayerSpec &l = kLayers[i];
+        const int wi = tensor_index(std::string(l.key) + ".weight"), bi = tensor_index(std::string(l.key) + ".bias");
+        if (wi < 0 || bi < 0 || !tensors[wi] || !tensors[bi]) ND_FAIL(ND_EINVAL, "nd_utnet_pack_weights_device: missing tensor %s.{weight,bias}", l.key);
+        const int ci = lcin(l, funit), co = lcout(l, funit);
+        if (i == kNumLayers - 1) {
+            ND_HIP(hipMemcpyAsync(blob + bl.off[i], tensors[wi], sizeof(float) * 3 * ci, hipMemcpyDeviceToDevice, s));
+            ND_HIP(hipMemcpyAsync(blob + bl.off[i] + 3 * ci, tensors[bi], sizeof(float) * 3, hipMemcpyDeviceToDevice, s));
+        } else {
+            ND_TRY(nd_pack_layer_device(l.kind, ci, co, tensors[wi], tensors[bi], blob + bl.off[i], s));
+            if (bl.woff[i]) ND_TRY(nd_pack_wino_device(kWinoTile, l.kind, ci, co, tensors[wi], tensors[bi], blob + bl.woff[i], s));
+            if (bl.w1off[i]) ND_TRY(nd_pack_w1d_device(kW1dTile, l.kind, ci, co, tensors[wi], tensors[bi], blob + bl.w1off[i], s));
+            if (bl.w1off2[i]) ND_TRY(nd_pack_w1d_device(2, l.kind, ci, co, tensors[wi], tensors[bi], blob + bl.w1off2[i], s));
+        }
+        if (l.prelu >= 0) {
+            std::string k(l.key);
+            const size_t dot = k.rfind('.');
+            const std::string an = k.substr(0, dot + 1) + std::to_string(atoi(k.c_str() + dot + 1) + 1) + ".weight";
+            const int ai = tensor_index(an);
+            if (ai >= 0 && tensors[ai]) {
+                ND_HIP(hipMemcpyAsync(blob + l.prelu, tensors[ai], sizeof(float), hipMemcpyDeviceToDevice, s));
+            } else {
+                const float dflt = 0.25f;
+                ND_HIP(hipMemcpyAsync(blob + l.prelu, &dflt, sizeof(float), hipMemcpyHostToDevice, s));
+                ND_HIP(hipStreamSynchronize(s));   // (dflt lives on this stack frame)
+            }
+        }
+    }
+    return ND_OK;
+}
+
 extern "C" size_t nd_utnet_workspace_bytes_hw(int funit, int h, int w, int batch, int dtype) {
     if (check_net(funit, h, w, batch, dtype) != ND_OK) return 0;
     return make_plan(funit, h, w, batch, batch, nullptr, dtype).bytes;

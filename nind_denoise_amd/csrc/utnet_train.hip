@@ -208,72 +208,6 @@ __global__ __launch_bounds__(64) void k_final_wgrad2(const f32x4 *__restrict__ p
     }
 }
 
-// device-side weight packing (same map as pack.hip's host packer, fp32): nw packed weights followed by MT*32 biases
-__global__ void k_pack_dev(int kind, int cin, int cout, int M, int KB, int taps, const float *__restrict__ w,
-                           const float *__restrict__ bias, float *__restrict__ packed, long nw, int nb) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < nw) {
-        const int s = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
-        long rest = idx >> 8;
-        const int t = (int)(rest % taps);
-        rest /= taps;
-        const int kb = (int)(rest % KB), mt = (int)(rest / KB);
-        const int m = 32 * mt + (lane & 31), ci = 8 * kb + 4 * (lane >> 5) + s;
-        float v = 0.f;
-        if (m < M && ci < cin) {
-            switch (kind) {
-                case ND_CONV3: v = w[((long)m * cin + ci) * 9 + t]; break;
-                case ND_CONVT3: v = w[((long)ci * cout + m) * 9 + (8 - t)]; break;
-                case ND_CONVT2S2: {
-                    const int ab = m / cout, co = m - ab * cout;
-                    v = w[((long)ci * cout + co) * 4 + ab];
-                    break;
-                }
-                case ND_CONV2S2: v = w[((long)m * cin + ci) * 4 + t]; break;
-                default: v = w[(long)m * cin + ci]; break;
-            }
-        }
-        packed[idx] = v;
-    } else if (idx < nw + nb) {
-        const int m = (int)(idx - nw);
-        packed[idx] = (m < M && bias) ? bias[kind == ND_CONVT2S2 ? m % cout : m] : 0.f;
-    }
-}
-
-// the same for the fused 1-D Winograd F(4,3) form of a 3x3 layer (conv_w1d.hip: nd_w1d_pack): [mt][kb][ky*6 + xi][lane][4] + bias
-__global__ void k_pack_w1d_dev(int kind, int cin, int cout, int KB, const float *__restrict__ w, const float *__restrict__ bias,
-                               float *__restrict__ packed, long nw, int nb) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < nw) {
-        const int s = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
-        long rest = idx >> 8;
-        const int plane = (int)(rest % 18);
-        rest /= 18;
-        const int kb = (int)(rest % KB), mt = (int)(rest / KB);
-        const int ky = plane / 6, xi = plane - 6 * ky;
-        const int m = 32 * mt + (lane & 31), ci = 8 * kb + 4 * (lane >> 5) + s;
-        float v = 0.f;
-        if (m < cout && ci < cin) {
-            float g[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-                g[k] = kind == ND_CONV3 ? w[((long)m * cin + ci) * 9 + ky * 3 + k] : w[((long)ci * cout + m) * 9 + (8 - (ky * 3 + k))];
-            switch (xi) {
-                case 0: v = g[0] / 4.f; break;
-                case 1: v = -(g[0] + g[1] + g[2]) / 6.f; break;
-                case 2: v = -(g[0] - g[1] + g[2]) / 6.f; break;
-                case 3: v = g[0] / 24.f + g[1] / 12.f + g[2] / 6.f; break;
-                case 4: v = g[0] / 24.f - g[1] / 12.f + g[2] / 6.f; break;
-                default: v = g[2]; break;
-            }
-        }
-        packed[idx] = v;
-    } else if (idx < nw + nb) {
-        const int m = (int)(idx - nw);
-        packed[idx] = (m < cout && bias) ? bias[m] : 0.f;
-    }
-}
-
 // Adam with amsgrad, torch.optim.Adam semantics (nn_common.py:185): no weight decay
 __global__ void k_adam(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
                        float *__restrict__ vmax, long n, float lr, float b1, float b2, float eps, float bc1, float bc2,
@@ -524,7 +458,6 @@ extern "C" int nd_utnet_train_step(int funit, const float *params, float *grads,
     const ParamLayout pl = param_layout(f);
     const BlobLayout bl = blob_layout(f, ND_F32, false, true);
     // 3x3 layers whose rows fit its LDS images run the fused 1-D Winograd kernel, forward and data gradient (else the direct one)
-    static_assert(kW1dTile == 4, "k_pack_w1d_dev packs the F(4,3) planes");
     unsigned char fwd_w1[kNumLayers] = {}, bwd_w1[kNumLayers] = {};
     for (const Step &st : kSteps) {
         if (st.layer < 0) continue;
@@ -556,28 +489,20 @@ extern "C" int nd_utnet_train_step(int funit, const float *params, float *grads,
         {
             const int MT = nd_mtiles(l.kind, co), KB = nd_kblocks(ci), taps = nd_taps(l.kind);
             const int M = l.kind == ND_CONVT2S2 ? 4 * co : co;
-            if (fwd_w1[i]) {
-                const long nw = (long)MT * KB * 18 * 256;
-                hipLaunchKernelGGL(k_pack_w1d_dev, dim3((unsigned)((nw + MT * 32 + 255) / 256)), dim3(256), 0, s, l.kind, ci, co, KB, w, b,
-                                   fblob + bl.off[i], nw, MT * 32);
-            } else {
-                const long nw = (long)MT * KB * taps * 256;
-                hipLaunchKernelGGL(k_pack_dev, dim3((unsigned)((nw + MT * 32 + 255) / 256)), dim3(256), 0, s, l.kind, ci, co, M, KB,
-                                   taps, w, b, fblob + bl.off[i], nw, MT * 32);
-            }
+            (void)MT; (void)KB; (void)taps; (void)M;
+            if (fwd_w1[i])
+                nd_pack_w1d_device(kW1dTile, l.kind, ci, co, w, b, fblob + bl.off[i], s);
+            else
+                nd_pack_layer_device(l.kind, ci, co, w, b, fblob + bl.off[i], s);
         }
         if (i > 0) {   // transposed role: cin' = co, cout' = ci, no bias
             const int kt = transposed_kind(l.kind);
             const int MT = nd_mtiles(kt, ci), KB = nd_kblocks(co), taps = nd_taps(kt);
-            if (bwd_w1[i]) {
-                const long nw = (long)MT * KB * 18 * 256;
-                hipLaunchKernelGGL(k_pack_w1d_dev, dim3((unsigned)((nw + MT * 32 + 255) / 256)), dim3(256), 0, s, kt, co, ci, KB, w,
-                                   (const float *)nullptr, bblob + bb.off[i], nw, MT * 32);
-            } else {
-                const long nw = (long)MT * KB * taps * 256;
-                hipLaunchKernelGGL(k_pack_dev, dim3((unsigned)((nw + MT * 32 + 255) / 256)), dim3(256), 0, s, kt, co, ci, ci, KB, taps,
-                                   w, (const float *)nullptr, bblob + bb.off[i], nw, MT * 32);
-            }
+            (void)MT; (void)KB; (void)taps;
+            if (bwd_w1[i])
+                nd_pack_w1d_device(kW1dTile, kt, co, ci, w, nullptr, bblob + bb.off[i], s);
+            else
+                nd_pack_layer_device(kt, co, ci, w, nullptr, bblob + bb.off[i], s);
         }
     }
     ND_HIP(hipGetLastError());

@@ -59,6 +59,7 @@ class UtNet(nn.Module):
             g = groups[name]
             self.add_module(name, nn.Sequential(*[g[i] for i in sorted(g)]) if isinstance(g, dict) else g)
         self._packed = {}         # dtype -> (key, device blob)
+        self.pack_on_device = True   # fp32: build the packed blob in HBM (nd_utnet_pack_weights_device); False: host packer
         self._workspaces = {}     # (device, h, w, batch, dtype) -> uint8 tensor
         self.max_cached_workspaces = 2
         self.compute_dtype = "f32"   # storage of activations + weights inside the conv stack: "f32" | "bf16" | "f16"
@@ -88,23 +89,32 @@ class UtNet(nn.Module):
         lib = _lib.load()
         sd = self.state_dict()
         names = _lib.utnet_tensor_names()
-        host = []
-        ptrs = (ctypes.c_void_p * len(names))()
-        for i, n in enumerate(names):
-            if n in sd:
-                t = sd[n].detach().to(device="cpu", dtype=torch.float32).contiguous()
-                host.append(t)
-                ptrs[i] = t.data_ptr()
-            else:
-                ptrs[i] = None  # activation without parameters (ELU / Hardswish)
         nbytes = lib.nd_utnet_packed_bytes(self.funit, self._dt)
         if nbytes == 0:
             raise ValueError(f"UtNet: funit={self.funit} is not supported by the HIP path for {self.compute_dtype} "
                              "(multiple of 8 for f32, of 16 for bf16 / f16)")
-        blob = torch.empty(nbytes // 4, dtype=torch.float32)
-        _lib.check(lib.nd_utnet_pack_weights(self.funit, self._dt, ptrs, len(names), blob.data_ptr(), nbytes),
-                   "nd_utnet_pack_weights")
-        dev_blob = blob.to(device)
+        on_device = self.compute_dtype == "f32" and self.pack_on_device
+        where = device if on_device else "cpu"     # fp32: pack in HBM (device-side packers); 16-bit: on the host
+        keep = []
+        ptrs = (ctypes.c_void_p * len(names))()
+        for i, n in enumerate(names):
+            if n in sd:
+                t = sd[n].detach().to(device=where, dtype=torch.float32).contiguous()
+                keep.append(t)
+                ptrs[i] = t.data_ptr()
+            else:
+                ptrs[i] = None  # activation without parameters (ELU / Hardswish)
+        if on_device:
+            dev_blob = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+            with torch.cuda.device(device):
+                _lib.check(lib.nd_utnet_pack_weights_device(self.funit, self._dt, ptrs, len(names), dev_blob.data_ptr(), nbytes,
+                                                            _lib.stream_ptr(device)), "nd_utnet_pack_weights_device")
+                torch.cuda.current_stream(device).synchronize()     # `keep` may be freed after this
+        else:
+            blob = torch.empty(nbytes // 4, dtype=torch.float32)
+            _lib.check(lib.nd_utnet_pack_weights(self.funit, self._dt, ptrs, len(names), blob.data_ptr(), nbytes),
+                       "nd_utnet_pack_weights")
+            dev_blob = blob.to(device)
         self._packed[self.compute_dtype] = (key, dev_blob)
         return dev_blob
 

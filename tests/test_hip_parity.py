@@ -458,6 +458,31 @@ def test_utnet_f64_smallest_tile_and_many_tiles(dev):
     assert (yb[255] - yb[0]).abs().max().item() < 1e-5 and (yb[258] - yb[0]).abs().max().item() < 1e-5   # 255, 258 = tile 0 again
 
 
+def test_device_packed_weights_equal_host_packed(dev):
+    # model load packs the fp32 blob (direct + both Winograd forms) in HBM; the host packer is the reference layout
+    from nind_denoise_amd.networks.UtNet import UtNet
+    for funit in (16, 64):
+        sd = synth.make_utnet_state_dict(funit=funit, seed=3)
+        net = UtNet(funit=funit)
+        net.load_state_dict(sd)
+        net = net.eval().to(dev)
+        b_dev = net.packed_weights(dev).cpu()
+        net.pack_on_device = False
+        net._packed.clear()
+        b_host = net.packed_weights(dev).cpu()
+        assert b_dev.shape == b_host.shape
+        scale = b_host.abs().max().item()
+        err = (b_dev - b_host).abs().max().item()                            # (plain floats below: never let pytest render a
+        pad_leak = b_dev[b_host == 0].abs().max().item()                     #  150 M-element tensor into a failure message)
+        assert err <= 2e-6 * scale, err                                      # Winograd weights: fp32 vs double transform
+        assert pad_leak <= 2e-6 * scale, pad_leak                            # padding rows / channels / gaps stay (numerically) zero
+        x = torch.rand(1, 3, 120, 120, generator=torch.Generator().manual_seed(1)).to(dev)
+        y_host = net(x)
+        net.pack_on_device = True
+        net._packed.clear()
+        assert (net(x) - y_host).abs().max().item() < 1e-6
+
+
 def test_utnet_rejects_invalid_cs_and_cpu(dev):
     from nind_denoise_amd.networks.UtNet import UtNet
     net = UtNet(funit=8).to(dev)
