@@ -1,4 +1,4 @@
-// 3x3 convolution with a 1-D Winograd F(2,3) along x inside the implicit-GEMM kernel (fp32 inference, narrow full-resolution layers).
+// 3x3 convolution with a 1-D Winograd F(2,3) | F(4,3) along x inside the implicit-GEMM kernel (fp32 inference, narrow full-resolution layers).
 //
 // The 64-channel layers of UtNet are HBM-bound in any multi-pass Winograd form (winograd.hip) and MFMA-bound in the direct
 // form (conv_qp.inc).  This kernel keeps the direct kernel's structure -- persistent workgroups, LDS-DMA halo images of the RAW
@@ -111,8 +111,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_w1d(ConvParams p) {
         }
     if (nsteps == 0) return;
 
-    // (image, compact PAIR index) of the l-th pair of N tile nb  (p.Wv = pairs per row, p.PV = pairs per image)
-    auto pair_of = [&](int nb, int l, int &img, int &r) -> bool {
+    // (image, compact GROUP index) of the l-th pixel group of N tile nb  (p.Wv = groups per row, p.PV = groups per image)
+    auto group_of = [&](int nb, int l, int &img, int &r) -> bool {
         bool ok;
         if (p.tpi) {
             img = nb / p.tpi;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_w1d(ConvParams p) {
     };
     auto tile_q0 = [&](int nb) -> long {
         int img, r;
-        pair_of(nb, 0, img, r);
+        group_of(nb, 0, img, r);
         return q_of(img, r);
     };
 
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_w1d(ConvParams p) {
     auto lane_offset = [&](int w) -> int {
         const int nb = decode(w).tile / p.n_tiles_m;
         int img, r;
-        pair_of(nb, wn * 32 + j, img, r);
+        group_of(nb, wn * 32 + j, img, r);
         const int left = p.wpx - T * (r % p.Wv);
         keep = left + 2 < NP ? left + 2 : NP;
         return WBYTES + h * planeB + (int)(q_of(img, r) - tile_q0(nb)) * 16;
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_w1d(ConvParams p) {
     auto epilogue = [&](int id) {
         const int nb = id / p.n_tiles_m, mb = id - nb * p.n_tiles_m;
         int bi, r;
-        const bool valid = pair_of(nb, wn * 32 + j, bi, r);
+        const bool valid = group_of(nb, wn * 32 + j, bi, r);
         const int y = r / p.Wv, xp = r - y * p.Wv;
         const long pix = (long)bi * p.Po + (long)(y + p.opad) * p.Wo + T * xp + p.opad;
         const int left = p.wpx - T * xp;   // valid pixels of this group (the last group of a row may hang over its end)
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_w1d(ConvParams p) {
     }
 }
 
-// workgroup shapes: 64 output channels x 256 groups (T = 2: 512 pixels, 2 x 32 rows per wave; T = 4: 1024 pixels... see below)
+// workgroup shapes: 64 output channels x 512 pixels either way
 struct W1Shape { int T, mblk, groups, threads, taps; };
 constexpr int kW1dStages = 2;
 //   T = 2: MR 2, WM 1, WN 8 -> 64 rows x 256 pairs (512 pixels), 8 accumulator tiles per wave
