@@ -1,24 +1,33 @@
 #!/usr/bin/env python3
 """Headline benchmark: megapixels/s denoised, UtNet(64,'PReLU') fp32, 24 MP synthetic frames, cs=264/ucs=200/ol=64.
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+    python bench.py --gpus N --steps K --warmup W            (N > 1: this process spawns the N ranks itself)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (also fine: ranks from the env)
 
 A "step" is one 6000x4000 frame through the device-resident crop -> UtNet -> stitch loop (BASELINE.json configs[1],
 geometry "G24" of SURVEY.md section 8: cs=264 is the valid tile size nearest to the named 256, which the reference
-network itself rejects).  The frame is resident in HBM when the timed region starts.  With N > 1 the tile index range
-of every frame is split into N contiguous shards (one rank per GPU); inside the timed region rank 0 sends every rank
-the image rows its shard reads (RCCL point-to-point over xGMI), every rank denoises its shard into its own canvas and
-rank 0 receives and adds the canvas row bands (nind_denoise_amd/dist.py) -> total work per step is fixed: "strong".
+network itself rejects).  The frame is resident in HBM when the timed region starts and the stitched canvas is in HBM when
+it ends.  With N > 1 the tile index range of every frame is split into N contiguous shards (one rank per GPU); inside the
+timed region rank 0 sends every rank the image rows its shard reads (RCCL point-to-point over xGMI), every rank denoises its
+shard into its own canvas and rank 0 receives and adds the canvas row bands (nind_denoise_amd/dist.py): total work per step
+is fixed -> "strong".  `--frames F` is BASELINE configs[2]'s shape instead: F frames per step dealt round-robin to the ranks
+(frame-level sharding, no per-frame exchange; work per step is fixed by F, so more ranks finish a step sooner).
 
-One JSON line on rank 0.  `roofline` prices the conv_qp_f32 kernel family (all 22 MFMA conv launches of the stack)
-against the fp32 MFMA peak with HIP events recorded on the launch stream; `cpu_baseline` times the oracle (torch CPU
-fp32, the same primitives the reference runs) on a bounded sample of the same frame's tiles.
+One JSON line on rank 0:
+  roofline      the dominant kernel by time (conv_w1d, the fused 1-D Winograd 3x3 kernel on the fp32 path): MFMA-EXECUTED
+                FLOP / HIP-event time on the launch stream / MFMA peak (<= 1 by construction); the algorithmic
+                (direct-convolution) rate is reported beside it, and `families` prices every kernel family against its own
+                bound (transform passes against HBM)
+  parity        max |HIP - oracle| over the tiles the cpu_baseline leg pushes through the oracle anyway
+  cpu_baseline  the oracle (torch CPU fp32, the primitives the reference runs) on a bounded sample of the same frame's tiles,
+                in grad mode (as the reference runs, denoise_image.py:246) and under no_grad
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,8 +35,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# /opt/skills/guides/MI355X_MICROARCH.md: "Peak FP32 (matrix)" 157.3 TFLOP/s; "Peak BF16/FP16 MFMA ~2.5 PF dense"
+# /opt/skills/guides/MI355X_MICROARCH.md: "Peak FP32 (matrix)" 157.3 TFLOP/s; "Peak BF16/FP16 MFMA ~2.5 PF dense"; HBM 8 TB/s
 PEAK_MFMA_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0}
+PEAK_HBM_TBS = 8.0
+METRIC = "megapixels/sec denoised, UtNet cs=256 on 24 MP frames, 1/2/4/8 MI355X"
+# ND_BENCH_REHEARSAL=1: rehearse the N > 1 code path on a box with fewer GPUs -- every rank on GPU 0, messages over gloo
+# (host-staged; RCCL refuses two ranks on one device).  Exercises the launcher, the shard loop and the exchange logic, not
+# the transport; its numbers are not benchmark results and the JSON line says so.
+REHEARSAL = os.environ.get("ND_BENCH_REHEARSAL", "") == "1"
 
 
 def log(msg):
@@ -65,78 +80,90 @@ def parse():
     ap.add_argument("--funit", type=int, default=64)
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"],
                     help="storage inside the conv stack; f32 is the headline configuration (exact-fp32 MFMA), bf16 / f16 are "
-                         "BASELINE configs 3 / 4 (16-bit storage, fp32 accumulate)")
-    ap.add_argument("--cpu-sample-tiles", type=int, default=0, help="0: sized for ~15 s of CPU work")
+                         "BASELINE configs 2 / 3 (16-bit storage, fp32 accumulate)")
+    ap.add_argument("--frames", type=int, default=0,
+                    help="> 0: BASELINE configs[2]'s shape -- a step is this many frames, dealt round-robin to the ranks "
+                         "(frame-level sharding, no per-frame exchange)")
+    ap.add_argument("--cpu-sample-tiles", type=int, default=0, help="0: sized for ~10 s of CPU work per mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-winograd", action="store_true", help="direct convolution on every layer (A/B switch)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-host-leg", action="store_true", help="skip the host->host (PCIe-inclusive) measurement")
     return ap.parse_args()
 
 
-def lib_winograd_on():
-    from nind_denoise_amd import _lib
-    lib = _lib.load()
-    was = lib.nd_conv_winograd_enable(1)
-    lib.nd_conv_winograd_enable(was)
-    return bool(was)
+# ------------------------------------------------------------------------------------------------ rank launcher
 
+def spawn_ranks(n):
+    """`bench.py --gpus N` without a launcher: start N fresh rank processes BEFORE this process touches the GPU, relay rank 0's
+    JSON line, fail if any rank fails.  (Never re-exec a process that has initialised the GPU.)"""
+    import torch   # importing torch and counting devices does not initialise the GPU
+    have = torch.cuda.device_count()
+    if have < n and not REHEARSAL:
+        sys.exit(f"bench.py --gpus {n}: only {have} GPU(s) visible")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    # relay rank 0's stdout; if any rank dies, end the others (by their exact pids) instead of leaving them in a collective
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            failed = True
+            time.sleep(5)      # let the failing rank's message reach stderr, and the others fail on their own if they will
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.2)
+    rcs = [p.wait() for p in procs]
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(c for c in chunks if c).decode(errors="replace"))
+    sys.stdout.flush()
+    if failed or any(rcs):
+        sys.exit(f"bench.py: rank exit codes {rcs}")
+
+
+# ------------------------------------------------------------------------------------------------ roofline
 
 def conv_stack_profile(net, cs, batch, dev, reps=3):
-    """HIP-event timing of every launch of the conv stack for one batch (median over reps)."""
+    """HIP-event timing of every launch of the conv stack for one batch (median over reps); the library reports which kernel
+    family ran each layer and the FLOP its matrix cores executed (nd_step_profile, include/nind_hip.h)."""
     import numpy as np
-    import torch
     from nind_denoise_amd import _lib
     lib = _lib.load()
     blob = net.packed_weights(dev)
     ws = net.workspace(cs, batch, dev)
     n = 26
-    ms = (ctypes.c_float * n)()
-    fl = (ctypes.c_double * n)()
-    isc = (ctypes.c_int * n)()
+    arr = (_lib.StepProfile * n)()
     runs = []
     for _ in range(reps + 1):
-        _lib.check(lib.nd_utnet_profile_stack(net.funit, _lib.ACT[net.activation], _lib.DTYPE[net.compute_dtype], blob.data_ptr(), batch, cs,
-                                              ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev), ms, fl, isc, n))
-        runs.append(list(ms))
+        _lib.check(lib.nd_utnet_profile_stack(net.funit, _lib.ACT[net.activation], _lib.DTYPE[net.compute_dtype], net.flags,
+                                              blob.data_ptr(), batch, cs, ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev),
+                                              ctypes.cast(arr, ctypes.c_void_p), n))
+        runs.append([(a.ms, a.ms_xform_in, a.ms_gemm, a.ms_xform_out) for a in arr])
     med = np.median(np.array(runs[1:]), axis=0)
-    steps = [dict(name=lib.nd_utnet_step_name(i).decode(), ms=float(med[i]), flop=float(fl[i]), conv=bool(isc[i]))
-             for i in range(n)]
+    steps = []
+    for i, a in enumerate(arr):
+        steps.append(dict(name=lib.nd_utnet_step_name(i).decode(), form=_lib.FORM_NAMES[a.form], kind=a.kind, ms=float(med[i][0]),
+                          ms_xform_in=float(med[i][1]), ms_gemm=float(med[i][2]), ms_xform_out=float(med[i][3]), flop=a.flops,
+                          mfma_flop=a.mfma_flops, bytes=a.bytes, xform_bytes_in=a.xform_bytes_in, xform_bytes_out=a.xform_bytes_out))
     return steps
 
 
-def executed_flop(name, flop, cs, batch, funit, dtype):
-    """MFMA-executed FLOP of one conv-stack step (csrc/utnet_net.h: wino_layer): 36 GEMMs of Cout x Cin x tiles for the 3x3 layers in
-    three-pass Winograd F(4x4,3x3) form, 18 weight planes per group of 4 pixels for the ones in fused 1-D F(4,3) form, the
-    algorithmic FLOP for everything else."""
-    import math
-    f, h = funit, cs + 4
-    shapes = {}
-    for n, (ci, co) in enumerate([(3, f), (f, 2 * f), (2 * f, 4 * f), (4 * f, 8 * f)], start=1):
-        shapes[f"convs{n}.0"] = (ci, co, h - 2)
-        shapes[f"convs{n}.2"] = (co, co, h - 4)
-        h = (h - 4) // 2
-    shapes["bottom.0"] = (8 * f, 16 * f, h - 2)
-    shapes["bottom.2"] = (16 * f, 16 * f, h)
-    c = 16 * f
-    for n in range(1, 5):
-        h *= 2
-        shapes[f"tconvs{n}.0"] = (c, c // 2, h + 2)
-        shapes[f"tconvs{n}.2"] = (c // 2, c // 2, h + 4)
-        h += 4
-        c //= 2
-    if name not in shapes or dtype != "f32":
-        return flop
-    ci, co, hout = shapes[name]
-    if ci >= 128 and co >= 128 and ci * co >= 128 * 256:
-        return 36 * 2.0 * ci * co * math.ceil(hout / 4) ** 2 * batch            # three-pass F(4x4,3x3): 36 GEMMs
-    cip = (ci + 7) // 8 * 8
-    return 3 * 6 * 2.0 * cip * co * hout * math.ceil(hout / 4) * batch           # 1-D F(4,3) in the implicit-GEMM kernel: 18 planes per 4 pixels
-
-
-def pmc_traffic(cs, batch, funit):
-    """HBM bytes per launch of the dominant kernel (conv_w1d, the fused 1-D Winograd 3x3 kernel) from the committed rocprofv3 PMC passes
-    (FETCH_SIZE and WRITE_SIZE collected in separate runs, gfx950 read correction applied -- profiles/*_pmc_summary.json).
-    Counters cannot be read inside the timed run, so this is null unless a profile of the same configuration exists."""
+def pmc_traffic(kernel_prefix, cs, batch, funit):
+    """HBM bytes per launch of one kernel from the newest committed rocprofv3 PMC summary of the same configuration
+    (FETCH_SIZE and WRITE_SIZE collected in separate passes, gfx950 read correction applied -- profiles/*_pmc_summary.json).
+    Counters cannot be read inside the timed run, so the figure comes from a stored profile and says so; None otherwise."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), reverse=True):
         try:
@@ -148,22 +175,100 @@ def pmc_traffic(cs, batch, funit):
         if (c.get("cs"), c.get("tiles_per_launch"), c.get("funit")) != (cs, batch, funit):
             continue
         rd = wr = n = 0
-        dominant = [n for n in d.get("kernels", {}) if n.startswith("conv_w1d<")] or \
-                   [n for n in d.get("kernels", {}) if n.startswith("conv_qp<0,") and ", 9, 1, false" in n]
-        for name, v in d.get("kernels", {}).items():   # the dominant kernel (fused 1-D Winograd 3x3; else the direct 3x3 variants)
-            if name in dominant and "hbm_read_bytes_mean" in v:
+        for name, v in d.get("kernels", {}).items():
+            if name.startswith(kernel_prefix) and "hbm_read_bytes_mean" in v and "hbm_write_bytes_mean" in v:
                 k = v["FETCH_SIZE"]["dispatches"]
                 rd += v["hbm_read_bytes_mean"] * k
                 wr += v["hbm_write_bytes_mean"] * k
                 n += k
         if n:
             return {"bytes_per_launch": round((rd + wr) / n), "read": round(rd / n), "write": round(wr / n),
-                    "launches_profiled": n, "source": os.path.relpath(f, ROOT)}
+                    "launches_profiled": n, "source": os.path.relpath(f, ROOT) + " (stored profile of this configuration, not this run)"}
     return None
 
 
-def cpu_baseline(frame, sd, cs, ucs, ol, n_tiles, threads):
-    """The oracle's crop -> UtNet -> stitch on `n_tiles` tiles of the frame (torch CPU fp32, grad mode off)."""
+def roofline_report(steps, dtype, cs, batch, funit):
+    peak = PEAK_MFMA_TFLOPS[dtype]
+    conv = [s for s in steps if s["form"] != "pool"]
+    fam = {}
+
+    def add(key, bound, ms, flop=0.0, mfma=0.0, byts=0.0, launches=1):
+        f = fam.setdefault(key, dict(bound=bound, ms=0.0, algorithmic_flop=0.0, mfma_flop=0.0, bytes=0.0, launches=0))
+        f["ms"] += ms
+        f["algorithmic_flop"] += flop
+        f["mfma_flop"] += mfma
+        f["bytes"] += byts
+        f["launches"] += launches
+
+    for s in steps:
+        if s["form"] == "pool":
+            add("k_maxpool2", "hbm", s["ms"], byts=s["bytes"])
+        elif s["form"] in ("w1d_f43", "w1d_f23"):
+            add("conv_w1d (3x3, 1-D Winograd F(4,3) fused into the implicit GEMM)", "mfma", s["ms"], s["flop"], s["mfma_flop"], s["bytes"])
+        elif s["form"] == "wino3p_f4x4":
+            if s["ms_gemm"] > 0:
+                add("conv_qp 1-tap (36 GEMMs of a three-pass Winograd F(4x4,3x3) layer)", "mfma", s["ms_gemm"], s["flop"], s["mfma_flop"],
+                    s["xform_bytes_in"] + s["xform_bytes_out"] - s["bytes"])
+                add("k_wino_input + k_wino_output (transform passes)", "hbm", s["ms_xform_in"] + s["ms_xform_out"],
+                    byts=s["xform_bytes_in"] + s["xform_bytes_out"], launches=2)
+            else:   # batches above one Winograd chunk: no split of the layer's time
+                add("three-pass Winograd layers (transforms + GEMMs)", "mfma", s["ms"], s["flop"], s["mfma_flop"], s["bytes"], launches=3)
+        elif s["kind"] == 2:
+            add("conv_qp up (ConvTranspose2d 2x2 s2)", "mfma", s["ms"], s["flop"], s["mfma_flop"], s["bytes"])
+        else:
+            add("conv_qp direct 3x3", "mfma", s["ms"], s["flop"], s["mfma_flop"], s["bytes"])
+    total_ms = sum(s["ms"] for s in steps)
+    families = []
+    for k, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]):
+        row = dict(kernel=k, bound=f["bound"], ms_per_batch=round(f["ms"], 4), share_of_stack=round(f["ms"] / total_ms, 4), launches=f["launches"])
+        if f["bound"] == "mfma":
+            ach = f["mfma_flop"] / (f["ms"] * 1e-3) / 1e12
+            row.update(achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
+                       algorithmic_tflops=round(f["algorithmic_flop"] / (f["ms"] * 1e-3) / 1e12, 2))
+        else:
+            ach = f["bytes"] / (f["ms"] * 1e-3) / 1e12
+            row.update(achieved=round(ach, 3), peak=PEAK_HBM_TBS, unit="TB/s", frac=round(ach / PEAK_HBM_TBS, 4),
+                       algorithmic_bytes_per_batch=round(f["bytes"]))
+        families.append(row)
+    # the dominant kernel by time among the MFMA families
+    dom = max((r for r in families if r["bound"] == "mfma"), key=lambda r: r["ms_per_batch"])
+    f = fam[dom["kernel"]]
+    is_w1d = dom["kernel"].startswith("conv_w1d")
+    traffic = pmc_traffic("conv_w1d<", cs, batch, funit) if (is_w1d and dtype == "f32") else None
+    stack_alg = sum(s["flop"] for s in conv) / (sum(s["ms"] for s in conv) * 1e-3) / 1e12
+    stack_exe = sum(s["mfma_flop"] for s in conv) / (sum(s["ms"] for s in conv) * 1e-3) / 1e12
+    return {
+        "bound": "mfma",
+        "kernel": dom["kernel"],
+        "achieved": dom["achieved"],
+        "peak": peak,
+        "unit": "TFLOP/s",
+        "frac": dom["frac"],
+        "definition": "MFMA-executed FLOP of the dominant kernel's launches (MFMA instructions x 4096) / their HIP-event time on the "
+                      "launch stream / peak; the algorithmic (direct-convolution, SURVEY.md 8d) rate is algorithmic_tflops",
+        "launches": f["launches"],
+        "avg_launch_ms": round(f["ms"] / f["launches"], 4),
+        "mfma_flop_per_launch": f["mfma_flop"] / f["launches"],
+        "algorithmic_flop_per_launch": f["algorithmic_flop"] / f["launches"],
+        "algorithmic_bytes_per_launch": round(f["bytes"] / f["launches"]),
+        "algorithmic_tflops": dom["algorithmic_tflops"],
+        "algorithmic_speedup": round(f["algorithmic_flop"] / f["mfma_flop"], 4),
+        "traffic": traffic["bytes_per_launch"] if traffic else None,
+        "traffic_detail": traffic,
+        "share_of_stack_time": dom["share_of_stack"],
+        "tiles_per_launch": batch,
+        "stack": {"ms_per_batch": round(total_ms, 4), "algorithmic_tflops": round(stack_alg, 2), "mfma_executed_tflops": round(stack_exe, 2),
+                  "mfma_executed_frac": round(stack_exe / peak, 4), "algorithmic_speedup": round(stack_alg / stack_exe, 4)},
+        "families": families,
+        "per_layer": [dict(name=s["name"], form=s["form"], ms=round(s["ms"], 4), algorithmic_tflops=round(s["flop"] / max(s["ms"], 1e-9) / 1e9, 2),
+                           mfma_tflops=round(s["mfma_flop"] / max(s["ms"], 1e-9) / 1e9, 2)) for s in steps],
+    }
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline + parity
+
+def cpu_baseline(frame, sd, cs, ucs, ol, ids, threads, grad_mode):
+    """The oracle's crop -> UtNet -> stitch on the tiles `ids` of the frame (torch CPU fp32).  Returns (seconds, outputs)."""
     import numpy as np
     import torch
     from oracle import networks as onet
@@ -171,77 +276,104 @@ def cpu_baseline(frame, sd, cs, ucs, ol, n_tiles, threads):
     torch.set_num_threads(threads)
     grid = otiler.TileGrid(frame.shape[2], frame.shape[1], cs, ucs, ol)
     canvas = np.zeros_like(frame)
-    ids = [int(i) for i in np.linspace(0, grid.size - 1, n_tiles)]
-    with torch.no_grad():
+    outs = []
+    with torch.set_grad_enabled(grad_mode):
+        if grad_mode:   # the reference's parameters are nn.Parameters: autograd records the forward (denoise_image.py:246)
+            sd = {k: v.clone().requires_grad_() for k, v in sd.items()}
         onet.utnet_forward(sd, torch.from_numpy(otiler.gather_tile(frame, grid, 0))[None])  # warm-up
         t0 = time.perf_counter()
         for i in ids:
             x = torch.from_numpy(otiler.gather_tile(frame, grid, i))[None]
-            y = onet.utnet_forward(sd, x).numpy()
+            y = onet.utnet_forward(sd, x).detach().numpy()
             otiler.stitch_add(canvas, y[0], grid, i)
+            outs.append(y[0])
         dt = time.perf_counter() - t0
-    return dt, grid.size
+    return dt, outs, grid.size
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)
+        return
     import numpy as np
     import torch
     import torch.distributed as dist
     from nind_denoise_amd import _lib, pipeline, synth
+    from nind_denoise_amd import dist as ndist
     from nind_denoise_amd.networks.UtNet import UtNet
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}")
-        args.gpus = world
+    args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if REHEARSAL:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if REHEARSAL:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     _lib.load()
-    if args.no_winograd:
-        _lib.load().nd_conv_winograd_enable(0)
 
     W, H, cs, ucs, ol = args.width, args.height, args.cs, args.ucs, args.ol
     sd = synth.make_utnet_state_dict(funit=args.funit, seed=123)
     net = UtNet(funit=args.funit)
     net.load_state_dict(sd)
     net = net.eval().to(dev).set_compute_dtype(args.dtype)
+    net.winograd = not args.no_winograd
     blob = net.packed_weights(dev)
-    if world > 1:
+    if world > 1 and not REHEARSAL:
         dist.broadcast(blob, src=0)  # one-time weight broadcast (rank 0 is the model owner)
 
-    frame_np = synth.make_frame(W, H, seed=24) if rank == 0 else None
-    frame = torch.from_numpy(frame_np).to(dev) if rank == 0 else torch.empty((3, H, W), dtype=torch.float32, device=dev)
-    from nind_denoise_amd import dist as ndist
     geo = ndist.Geo(W, H, cs, ucs, ol)
     total = geo.total
-    lo, hi = geo.shard(rank, world)
-    canvas = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
+    mp = W * H / 1e6
+    frame_np = None
 
     def compute(fr, cv, a, b):
         pipeline.denoise_frame(net, fr, cs, ucs, ol, batch=args.batch, tile_range=(a, b), canvas=cv)
 
-    def step():
-        if world > 1:
-            # rank 0 scatters input row bands, every rank denoises its tile shard, rank 0 gathers + adds the bands
-            ndist.denoise_frame_sharded(compute, frame, canvas, geo)
-        else:
-            canvas.zero_()
-            compute(frame, canvas, 0, total)
+    if args.frames > 0:
+        # configs[2] shape: a step = `frames` frames, frame f handled by rank f % world; a few distinct synthetic frames
+        # resident in HBM are cycled (the arithmetic does not depend on the pixel values)
+        mine = ndist.frame_shard(args.frames, rank, world)
+        pool = [torch.from_numpy(synth.make_frame(W, H, seed=s)).to(dev) for s in range(min(3, max(1, len(mine))))]
+        if rank == 0:
+            frame_np = pool[0].cpu().numpy()
+        canvas = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
+        lo, hi = 0, total
+
+        def step():
+            for k, _f in enumerate(mine):
+                canvas.zero_()
+                compute(pool[k % len(pool)], canvas, 0, total)
+        frames_per_step = args.frames
+    else:
+        frame_np = synth.make_frame(W, H, seed=24) if rank == 0 else None
+        frame = torch.from_numpy(frame_np).to(dev) if rank == 0 else torch.empty((3, H, W), dtype=torch.float32, device=dev)
+        lo, hi = geo.shard(rank, world)
+        canvas = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
+
+        def step():
+            if world > 1:
+                # rank 0 scatters input row bands, every rank denoises its tile shard, rank 0 gathers + adds the bands
+                ndist.denoise_frame_sharded(compute, frame, canvas, geo)
+            else:
+                canvas.zero_()
+                compute(frame, canvas, 0, total)
+        frames_per_step = 1
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    log(f"setup done: {total} tiles/frame, rank shard [{lo},{hi}), batch {args.batch}")
+    log(f"setup done: {total} tiles/frame, rank tile shard [{lo},{hi}), batch {args.batch}, frames/step {frames_per_step}")
     for i in range(args.warmup):
         step()
         torch.cuda.synchronize()
@@ -254,14 +386,20 @@ def main():
     dt = time.perf_counter() - t0
     log(f"timed {args.steps} steps in {dt:.3f} s")
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if REHEARSAL else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    mp = W * H / 1e6
-    value = mp * args.steps / dt
+    value = mp * frames_per_step * args.steps / dt
+    cfg_idx = 1 if args.dtype == "f32" else 2 if args.dtype == "bf16" else 3
+    if args.frames > 0:
+        par = f"frame-shard x{world} (frames dealt round-robin, no per-frame exchange)" if world > 1 else "single GPU"
+        what = f"{args.frames} {W}x{H} ({mp:.1f} MP) fp32 frames per step"
+    else:
+        par = f"tile-shard x{world} (P2P row-band scatter / gather at rank 0)" if world > 1 else "single GPU"
+        what = f"one {W}x{H} ({mp:.1f} MP) fp32 frame per step"
     out = {
-        "metric": "megapixels/sec denoised, UtNet cs=256 on 24 MP frames, 1/2/4/8 MI355X",
+        "metric": METRIC,
         "value": round(value, 4),
         "unit": "MP/s",
         "n_gpus": world,
@@ -272,70 +410,90 @@ def main():
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": args.dtype,
-        "data": "synthetic",
+        "data": "synthetic" + (" -- REHEARSAL: all ranks on one GPU over gloo, not a benchmark result" if REHEARSAL else ""),
         "config": {
-            "workload": f"configs[{1 if args.dtype == 'f32' else 2 if args.dtype == 'bf16' else 3}]: one {W}x{H} ({mp:.1f} MP) fp32 frame per step, "
-                        f"{args.dtype} storage in the conv stack (fp32 accumulate), UtNet(funit={args.funit},PReLU) random-init "
-                        f"(seed 123), cs={cs} (nearest valid to 256; the reference rejects 256) ucs={ucs} ol={ol} -> {total} tiles, "
-                        f"tiles per conv-stack launch {args.batch}, crop->infer->stitch device resident",
+            "workload": f"configs[{cfg_idx}]: {what}, {args.dtype} storage in the conv stack (fp32 accumulate), UtNet(funit={args.funit},PReLU) "
+                        f"random-init (seed 123), cs={cs} (nearest valid to the named size; the reference rejects 256 / 512) ucs={ucs} ol={ol} -> "
+                        f"{total} tiles/frame, tiles per conv-stack launch {args.batch}, crop->infer->stitch device resident (frame and canvas in HBM)",
             "tiles_per_frame": total,
+            "frames_per_step": frames_per_step,
             "flop_per_frame": net.flops_per_tile(cs) * total,
-            "parallelism": f"tile-shard x{world}" if world > 1 else "single GPU",
+            "parallelism": par,
         },
     }
 
     if rank == 0:
         flop_frame = net.flops_per_tile(cs) * total
-        out["end_to_end_tflops"] = round(flop_frame * args.steps / dt / 1e12, 3)
+        out["end_to_end_algorithmic_tflops"] = round(flop_frame * frames_per_step * args.steps / dt / 1e12, 3)
         if not args.no_roofline:
             # (N > 1: rank 0 profiles the conv stack at the size of its own tile shard; the other ranks wait at the end)
             b = min(args.batch, hi - lo)
             steps = conv_stack_profile(net, cs, b, dev)
             log("conv stack profile done")
-            conv_ms = sum(s["ms"] for s in steps if s["conv"])
-            conv_flop = sum(s["flop"] for s in steps if s["conv"])
-            achieved = conv_flop / (conv_ms * 1e-3) / 1e12
-            wino = args.dtype == "f32" and lib_winograd_on()
-            exe_flop = sum(executed_flop(s["name"], s["flop"], cs, b, args.funit, args.dtype if wino else "") for s in steps if s["conv"])
-            out["roofline"] = {
-                "bound": "mfma",
-                "kernel": f"conv_qp<{args.dtype}>: the 22 weighted layers of the UtNet conv stack per tile batch"
-                          + (" -- 1-D Winograd F(4,3) inside the 3x3 implicit-GEMM kernel (7 layers), 36 batched 1-tap GEMMs per three-pass "
-                             "Winograd F(4x4,3x3) layer (11 layers, layer time includes the two transform passes), 2x2-s2 transposed "
-                             "(4 layers)" if wino else ""),
-                "achieved": round(achieved, 3),
-                "peak": PEAK_MFMA_TFLOPS[args.dtype],
-                "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_MFMA_TFLOPS[args.dtype], 4),
-                "note": "achieved = ALGORITHMIC FLOP (direct-convolution count, SURVEY.md 8d) / time; with Winograd layers the matrix "
-                        "cores execute fewer FLOP than that, so the fraction can exceed 1 -- mfma_executed_* is what the MFMA pipe ran",
-                "mfma_executed_tflops": round(exe_flop / (conv_ms * 1e-3) / 1e12, 3),
-                "mfma_executed_frac": round(exe_flop / (conv_ms * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS[args.dtype], 4),
-                "traffic": (pmc_traffic(cs, b, args.funit) or {}).get("bytes_per_launch") if args.dtype == "f32" else None,
-                "traffic_unit": "HBM bytes per launch of the dominant kernel, conv_w1d (PMC FETCH_SIZE*2 + WRITE_SIZE)",
-                "traffic_detail": pmc_traffic(cs, b, args.funit) if args.dtype == "f32" else None,
-                "launches": len([s for s in steps if s["conv"]]),
-                "avg_launch_ms": round(conv_ms / max(1, len([s for s in steps if s["conv"]])), 4),
-                "algorithmic_flop_per_launch_avg": conv_flop / max(1, len([s for s in steps if s["conv"]])),
-                "tiles_per_launch": b,
-                "stack_ms_per_batch": round(sum(s["ms"] for s in steps), 4),
-                "per_layer": [dict(name=s["name"], ms=round(s["ms"], 4),
-                                   tflops=round(s["flop"] / max(s["ms"], 1e-9) / 1e9, 2)) for s in steps],
-            }
+            out["roofline"] = roofline_report(steps, args.dtype, cs, b, args.funit)
+        if not args.no_host_leg and world == 1:
+            # SURVEY.md 8(d)'s end-to-end definition: decoded fp32 frame in pinned host memory -> stitched frame in host memory,
+            # through the resident engine (H2D / compute / D2H overlapped over a ring of 3 slots).  Reported beside `value`.
+            from nind_denoise_amd.serve import FrameEngine
+            eng = FrameEngine(net, W, H, cs, ucs, ol, batch=args.batch, slots=3, device=dev)
+            src = torch.from_numpy(frame_np).pin_memory()
+            n_host = max(4, min(12, args.steps))
+            for _ in eng.run([src] * 2):
+                pass
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            cnt = 0
+            for _ in eng.run([src] * n_host, copy=False):
+                cnt += 1
+            dth = time.perf_counter() - t1
+            out["host_to_host"] = {"value": round(mp * cnt / dth, 4), "unit": "MP/s", "frames": cnt,
+                                   "note": "pinned host frame -> HBM -> crop/UtNet/stitch -> pinned host canvas, PCIe legs overlapped "
+                                           "with compute (serve.FrameEngine); `value` above is the HBM-resident rate"}
+            del eng
+            log("host-to-host leg done")
         if not args.no_cpu_baseline and world == 1:
             threads = min(host_cores(), 64)
-            n = args.cpu_sample_tiles or max(8, min(320, threads * 16))   # ~15 s of CPU work at ~0.05 s/tile
-            log(f"cpu baseline: {n} tiles on {threads} threads")
-            cdt, tot = cpu_baseline(frame_np, sd, cs, ucs, ol, n, threads)
-            log(f"cpu baseline done in {cdt:.1f} s")
+            n = args.cpu_sample_tiles or max(8, min(200, threads * 6))   # ~10 s of CPU work per mode at ~0.1 s/tile
+            ids = [int(i) for i in np.linspace(0, total - 1, n)]
+            log(f"cpu baseline: {n} tiles on {threads} threads, grad mode then no_grad")
+            cdt_g, _, tot = cpu_baseline(frame_np, sd, cs, ucs, ol, ids, threads, True)
+            cdt_n, outs, _ = cpu_baseline(frame_np, sd, cs, ucs, ol, ids, threads, False)
+            log(f"cpu baseline done in {cdt_g:.1f} + {cdt_n:.1f} s")
             out["cpu_baseline"] = {
-                "value": round(mp * (n / tot) / cdt, 5),
+                "value": round(mp * (n / tot) / cdt_g, 5),
                 "unit": "MP/s",
                 "cores": threads,
                 "kind": "port",
-                "sample": f"{n} of {tot} tiles of the same frame through oracle gather -> UtNet (torch CPU fp32, no_grad, "
-                          f"{threads} threads) -> stitch in {cdt:.2f} s, scaled by tiles",
+                "sample": f"{n} of {tot} tiles of the same frame through oracle gather -> UtNet (torch CPU fp32, {threads} threads) -> stitch, "
+                          f"scaled by tiles; grad mode as the reference runs (denoise_image.py:246, no no_grad) in {cdt_g:.2f} s",
+                "no_grad": {"value": round(mp * (n / tot) / cdt_n, 5), "seconds": round(cdt_n, 2)},
             }
+            # parity of the timed HIP path on those same tiles (the launch shape of the timed loop: `batch` tiles per launch)
+            img = torch.from_numpy(frame_np).to(dev)
+            worst = 0.0
+            scale = 0.0
+            psnr_min = float("inf")
+            per_launch = {}
+            for k, i in enumerate(ids):
+                per_launch.setdefault(i // args.batch, []).append((k, i))
+            for launch, members in per_launch.items():
+                first = launch * args.batch
+                cnt = min(args.batch, total - first)
+                x = pipeline.gather_tiles(img, cs, ucs, ol, first, cnt)
+                y = net(x)
+                for k, i in members:
+                    got = y[i - first].cpu().numpy()
+                    ref = outs[k]
+                    worst = max(worst, float(np.abs(got - ref).max()))
+                    scale = max(scale, float(np.abs(ref).max()))
+                    mse = float(np.mean((got - ref) ** 2))
+                    psnr_min = min(psnr_min, 10 * np.log10(float(ref.max() - ref.min()) ** 2 / max(mse, 1e-30)))
+                del x, y
+            out["parity"] = {"max_abs": worst, "max_abs_ref": scale, "min_psnr_db": round(psnr_min, 2), "tiles": n,
+                             "bar": "fp32: max_abs <= 1e-3 and <= 1e-3 * max_abs_ref" if args.dtype == "f32" else "16-bit storage: PSNR reported",
+                             "ok": bool(worst <= 1e-3 and worst <= 1e-3 * scale) if args.dtype == "f32" else bool(psnr_min >= 60.0),
+                             "note": f"HIP path at the timed launch shape ({args.batch} tiles per launch) vs the oracle outputs of the cpu_baseline leg"}
+            log(f"parity on {n} tiles: max abs {worst:.3e}")
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -51,6 +51,16 @@ typedef enum nd_dtype {
     ND_F16 = 2            /* fp16 storage of activations + weights, fp32 accumulate (v_mfma_f32_32x32x16_f16)  */
 } nd_dtype;
 
+/* Per-call arithmetic flags (bit set; 0 = the default path).  There is no process-wide switch: two calls with different
+ * flags may run concurrently on different streams. */
+typedef enum nd_flags {
+    ND_FLAG_NO_SPLITK = 1,    /* keep every output tile whole: no split-K tail, so a tile's bits do not depend on which other
+                                 tiles share its launch (the default splits the K loop of a launch's last, partial round of
+                                 workgroups over the idle CUs: deterministic, but fp32 sums re-associate by <= 1e-5)        */
+    ND_FLAG_DIRECT_CONV = 2   /* direct convolution on every 3x3 layer (default on the fp32 path: Winograd F(4x4,3x3) from
+                                 128 channels up, 1-D F(4,3) inside the implicit-GEMM kernel below; ~1e-5 re-association)   */
+} nd_flags;
+
 int nd_version(void);
 const char *nd_last_error(void);
 
@@ -101,12 +111,12 @@ int nd_utnet_workspace_init(void *workspace, size_t workspace_bytes, int funit, 
 size_t nd_utnet_workspace_bytes_hw(int funit, int h, int w, int batch, int dtype);
 int nd_utnet_workspace_init_hw(void *workspace, size_t workspace_bytes, int funit, int h, int w, int batch, int dtype,
                                void *stream);
-int nd_utnet_forward_hw(int funit, int act, int dtype, const void *packed_dev,
+int nd_utnet_forward_hw(int funit, int act, int dtype, int flags, const void *packed_dev,
                         const float *x_nchw, float *y_nchw, int batch, int h, int w,
                         void *workspace, size_t workspace_bytes, void *stream);
 
 /* UtNet.forward (UtNet.py:97-109): x_nchw [batch,3,cs,cs] -> y_nchw [batch,3,cs,cs], both float32 in HBM. */
-int nd_utnet_forward(int funit, int act, int dtype, const void *packed_dev,
+int nd_utnet_forward(int funit, int act, int dtype, int flags, const void *packed_dev,
                      const float *x_nchw, float *y_nchw, int batch, int cs,
                      void *workspace, size_t workspace_bytes, void *stream);
 
@@ -114,18 +124,30 @@ int nd_utnet_forward(int funit, int act, int dtype, const void *packed_dev,
  * device resident: gather(+mirror) -> UtNet -> useful crop -> seamless edges -> canvas +=.
  * tile_count <= batch of the workspace.  Equivalent to nd_tile_gather + nd_utnet_forward + nd_stitch_add
  * without materialising the NCHW tile batch. */
-int nd_utnet_denoise_tiles(int funit, int act, int dtype, const void *packed_dev,
+int nd_utnet_denoise_tiles(int funit, int act, int dtype, int flags, const void *packed_dev,
                            const float *img_chw, float *canvas_chw, int width, int height,
                            int cs, int ucs, int ol, int tile_begin, int tile_count, int batch,
                            void *workspace, size_t workspace_bytes, void *stream);
 
-/* Profiling entry point for the roofline report: one pass of the conv stack (22 MFMA conv launches + 4 pools, the
- * launches between the input pack and the final 1x1) with a HIP event recorded on `stream` between launches.
- * Synchronises the stream.  step_ms[i]: duration of launch i; step_flops[i]: its algorithmic FLOP for `batch` tiles
- * (0 for pools); is_conv[i]: 1 for conv_qp_f32 launches.  nd_utnet_step_name(i): reference layer key. */
-int nd_utnet_profile_stack(int funit, int act, int dtype, const void *packed_dev, int batch, int cs,
-                           void *workspace, size_t workspace_bytes, void *stream,
-                           float *step_ms, double *step_flops, int *is_conv, int max_steps);
+/* Profiling entry point for the roofline report: one pass of the conv stack (22 MFMA conv layers + 4 pools, the launches
+ * between the input pack and the final 1x1) with a HIP event recorded on `stream` between launches.  Synchronises the stream.
+ * nd_utnet_step_name(i): reference layer key of step i ("maxpool" for pools). */
+typedef struct nd_step_profile {
+    float ms;               /* duration of the step (all its launches)                                                      */
+    float ms_xform_in;      /* three-pass Winograd layers: input transform pass, GEMM launch, output transform pass (0 for   */
+    float ms_gemm;          /*   the other forms, and for batches above one Winograd chunk)                                  */
+    float ms_xform_out;
+    int form;               /* -1 pool; 0 direct implicit GEMM (conv_qp); 1 fused 1-D Winograd F(4,3) (conv_w1d); 2 F(2,3);  */
+                            /*   3 three-pass Winograd F(4x4,3x3): k_wino_input -> 36 GEMMs in one conv_qp launch -> k_wino_output */
+    int kind;               /* nd_layer_kind, -1 for pools                                                                  */
+    double flops;           /* algorithmic FLOP for `batch` tiles (SURVEY.md 2a convention; 0 for pools)                    */
+    double mfma_flops;      /* FLOP the matrix cores execute in that form (MFMA instructions x 4096)                        */
+    double bytes;           /* algorithmic HBM bytes: input + output activations + weights                                   */
+    double xform_bytes_in;  /* three-pass layers: algorithmic HBM bytes of the two transform passes                          */
+    double xform_bytes_out;
+} nd_step_profile;
+int nd_utnet_profile_stack(int funit, int act, int dtype, int flags, const void *packed_dev, int batch, int cs,
+                           void *workspace, size_t workspace_bytes, void *stream, nd_step_profile *steps, int max_steps);
 const char *nd_utnet_step_name(int i);
 
 /* ---------------------------------------------------------------- UNet (ThirdPartyNets.py:62-169, eval mode)
@@ -154,7 +176,7 @@ int nd_layer_pack(int kind, int cin, int cout, int dtype, const float *weight, c
 size_t nd_layer_workspace_bytes(int kind, int batch, int cin, int cout, int h, int w, int dtype);
 int nd_layer_forward(int kind, int act, float slope, int dtype, const void *packed_dev,
                      const float *x_nchw, int batch, int cin, int h, int w, int cout, float *y_nchw,
-                     void *workspace, size_t workspace_bytes, int variant, void *stream);
+                     void *workspace, size_t workspace_bytes, int variant, int flags, void *stream);
 /* nn.MaxPool2d(2) (UtNet.py:34) on NCHW float32 through the quad-planar pool kernel. */
 int nd_maxpool2_forward(const float *x_nchw, int batch, int c, int h, int w, float *y_nchw,
                         void *workspace, size_t workspace_bytes, void *stream);
@@ -176,15 +198,17 @@ int nd_layer_wgrad(int kind, const float *x_nchw, const float *dy_nchw, int batc
  *            + w_msssim * mean_n(1 - MS-SSIM_n(g, t)),        g = clip(net(x), 0, 1), t = target   (nn_common.py:198-241;
  *     the SSIM terms as in nd_ssim_loss_grad; MS-SSIM needs cs >= 161, so it cannot be used on 136-pixel crops)
  * x, target, y_out: [batch,3,cs,cs] NCHW fp32 in HBM (cs = 16k+56, e.g. 136 / 184); loss_out: one float in HBM.
+ * loss_cs: the criteria see the centre crop of loss_cs x loss_cs pixels of output and target (pt_ops.pt_crop_batch,
+ * nn_train.py:319-323; --loss_cs); the gradient is zero outside it.  0 or cs: the whole output.
  * nd_adam_step = torch.optim.Adam(lr, betas, eps, amsgrad) on the flat buffers (nn_common.py:185). */
 size_t nd_utnet_param_count(int funit);
 int nd_utnet_param_range(int funit, int tensor_idx, size_t *offset, size_t *count);
 size_t nd_utnet_train_blob_bytes(int funit);
 size_t nd_utnet_train_workspace_bytes(int funit, int cs, int batch);
 int nd_utnet_train_workspace_init(void *workspace, size_t workspace_bytes, int funit, int cs, int batch, void *stream);
-int nd_utnet_train_step(int funit, const float *params, float *grads, void *blobs, const float *x_nchw,
+int nd_utnet_train_step(int funit, int flags, const float *params, float *grads, void *blobs, const float *x_nchw,
                         const float *target_nchw, float *y_out_nchw, float w_l1, float w_mse, float w_ssim, float w_msssim,
-                        float *loss_out, int batch, int cs, void *workspace, size_t workspace_bytes, void *stream);
+                        float *loss_out, int batch, int cs, int loss_cs, void *workspace, size_t workspace_bytes, void *stream);
 int nd_adam_step(float *params, const float *grads, float *m, float *v, float *vmax, size_t n, float lr, float beta1,
                  float beta2, float eps, int step, int amsgrad, void *stream);
 
@@ -217,7 +241,8 @@ int nd_winograd_pack(int tile, int kind, int cin, int cout, const float *w, cons
                      size_t packed_bytes);
 size_t nd_layer_winograd_workspace_bytes(int tile, int kind, int batch, int cin, int cout, int h, int w);
 int nd_layer_forward_winograd(int tile, int kind, int act, float slope, const void *packed, const float *x, int batch,
-                              int cin, int h, int w, int cout, float *y, void *workspace, size_t workspace_bytes, void *stream);
+                              int cin, int h, int w, int cout, float *y, void *workspace, size_t workspace_bytes, int flags,
+                              void *stream);
 
 /* Kernel micro-benchmark: `iters` launches of one conv layer (variant -1 = automatic choice) on pseudo-random
  * quad-planar data carved from `workspace` (nd_layer_workspace_bytes + nd_layer_packed_bytes + 256 B); mean launch
@@ -231,16 +256,6 @@ int nd_winograd_bench(int tile, int kind, int batch, int cin, int cout, int h, i
 /* Name and average duration bookkeeping for bench.py: number of conv-kernel variants compiled in. */
 int nd_num_conv_variants(void);
 const char *nd_conv_variant_name(int variant);
-
-/* Split-K tail (on by default): the tiles of a launch's last, partial round of workgroups are cut along K so that the
- * idle CUs share them; the slices are added in a fixed order (deterministic), but the fp32 summation order differs from
- * the unsplit launch in the last bits.  Returns the previous setting.  Measurement switch; not needed for correctness. */
-int nd_conv_split_enable(int on);
-
-/* Winograd F(4x4, 3x3) form of the >= 128-channel 3x3 layers on the fp32 inference path (on by default; ~1e-5 relative
- * re-association error per layer) and 1-D F(4,3) inside the implicit-GEMM kernel on the narrower ones: 1.67x on the UtNet(64) conv
- * stack.  Returns the previous setting. */
-int nd_conv_winograd_enable(int on);
 
 #ifdef __cplusplus
 }

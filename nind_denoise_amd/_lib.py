@@ -13,6 +13,18 @@ ND_F32, ND_BF16, ND_F16 = 0, 1, 2
 DTYPE = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "f16": 2, "fp16": 2, "float16": 2}
 ACT = {"none": 0, "PReLU": 1, "ELU": 2, "Hardswish": 3}
 KIND = {"conv3": 0, "convT3": 1, "convT2s2": 2, "conv1": 3, "conv2s2": 4}
+# nd_flags (include/nind_hip.h): per-call arithmetic switches
+FLAG_NO_SPLITK, FLAG_DIRECT_CONV = 1, 2
+
+
+class StepProfile(ctypes.Structure):
+    """nd_step_profile of include/nind_hip.h"""
+    _fields_ = [("ms", c_float), ("ms_xform_in", c_float), ("ms_gemm", c_float), ("ms_xform_out", c_float),
+                ("form", c_int), ("kind", c_int), ("flops", c_double), ("mfma_flops", c_double), ("bytes", c_double),
+                ("xform_bytes_in", c_double), ("xform_bytes_out", c_double)]
+
+
+FORM_NAMES = {-1: "pool", 0: "direct", 1: "w1d_f43", 2: "w1d_f23", 3: "wino3p_f4x4"}
 
 
 class NindHipError(RuntimeError):
@@ -41,9 +53,9 @@ _SIGNATURES = {
     "nd_utnet_workspace_init": (c_int, [c_void_p, c_size_t] + [c_int] * 4 + [c_void_p]),
     "nd_utnet_workspace_bytes_hw": (c_size_t, [c_int] * 5),
     "nd_utnet_workspace_init_hw": (c_int, [c_void_p, c_size_t] + [c_int] * 5 + [c_void_p]),
-    "nd_utnet_forward_hw": (c_int, [c_int] * 3 + [c_void_p] * 3 + [c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
-    "nd_utnet_forward": (c_int, [c_int] * 3 + [c_void_p] * 3 + [c_int, c_int, c_void_p, c_size_t, c_void_p]),
-    "nd_utnet_denoise_tiles": (c_int, [c_int] * 3 + [c_void_p] * 3 + [c_int] * 8 + [c_void_p, c_size_t, c_void_p]),
+    "nd_utnet_forward_hw": (c_int, [c_int] * 4 + [c_void_p] * 3 + [c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "nd_utnet_forward": (c_int, [c_int] * 4 + [c_void_p] * 3 + [c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "nd_utnet_denoise_tiles": (c_int, [c_int] * 4 + [c_void_p] * 3 + [c_int] * 8 + [c_void_p, c_size_t, c_void_p]),
     "nd_unet_num_tensors": (c_int, []),
     "nd_unet_tensor_name": (c_char_p, [c_int]),
     "nd_unet_packed_bytes": (c_size_t, [c_int]),
@@ -52,19 +64,18 @@ _SIGNATURES = {
     "nd_unet_workspace_init": (c_int, [c_void_p, c_size_t] + [c_int] * 4 + [c_void_p]),
     "nd_unet_forward": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "nd_utnet_flops": (c_double, [c_int, c_int]),
-    "nd_utnet_profile_stack": (c_int, [c_int] * 3 + [c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p,
-                                                      POINTER(c_float), POINTER(c_double), POINTER(c_int), c_int]),
+    "nd_utnet_profile_stack": (c_int, [c_int] * 4 + [c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_int]),
     "nd_utnet_step_name": (c_char_p, [c_int]),
     "nd_layer_packed_bytes": (c_size_t, [c_int] * 4),
     "nd_layer_pack": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_size_t]),
     "nd_layer_workspace_bytes": (c_size_t, [c_int] * 7),
     "nd_layer_forward": (c_int, [c_int, c_int, c_float, c_int, c_void_p, c_void_p] + [c_int] * 5
-                         + [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+                         + [c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "nd_winograd_packed_bytes": (c_size_t, [c_int] * 3),
     "nd_winograd_pack": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_size_t]),
     "nd_layer_winograd_workspace_bytes": (c_size_t, [c_int] * 7),
     "nd_layer_forward_winograd": (c_int, [c_int, c_int, c_int, c_float, c_void_p, c_void_p] + [c_int] * 5
-                                  + [c_void_p, c_void_p, c_size_t, c_void_p]),
+                                  + [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "nd_maxpool2_forward": (c_int, [c_void_p] + [c_int] * 4 + [c_void_p, c_void_p, c_size_t, c_void_p]),
     "nd_layer_wgrad_workspace_bytes": (c_size_t, [c_int] * 6),
     "nd_layer_wgrad": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -73,8 +84,8 @@ _SIGNATURES = {
     "nd_utnet_train_blob_bytes": (c_size_t, [c_int]),
     "nd_utnet_train_workspace_bytes": (c_size_t, [c_int] * 3),
     "nd_utnet_train_workspace_init": (c_int, [c_void_p, c_size_t, c_int, c_int, c_int, c_void_p]),
-    "nd_utnet_train_step": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
-                                    c_float, c_float, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "nd_utnet_train_step": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
+                                    c_float, c_float, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "nd_adam_step": (c_int, [c_void_p] * 5 + [c_size_t, c_float, c_float, c_float, c_float, c_int, c_int, c_void_p]),
     "nd_ssim_workspace_bytes": (c_size_t, [c_int] * 4),
     "nd_ssim": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -87,8 +98,6 @@ _SIGNATURES = {
     "nd_winograd_bench": (c_int, [c_int] * 8 + [c_void_p, c_size_t, c_void_p, POINTER(c_float)]),
     "nd_num_conv_variants": (c_int, []),
     "nd_conv_variant_name": (c_char_p, [c_int]),
-    "nd_conv_split_enable": (c_int, [c_int]),
-    "nd_conv_winograd_enable": (c_int, [c_int]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

@@ -174,15 +174,10 @@ static SplitPlan plan_split(long ntiles, int nchunks, long slots, long max_items
 
 static int g_num_cus = 0;
 static const double kSplitOver = 3.0;
-static int g_split_on = 1;
-extern "C" int nd_conv_split_enable(int on) {
-    const int was = g_split_on;
-    g_split_on = on ? 1 : 0;
-    return was;
-}
 
+// max_items = 0 (no scratch, or ND_FLAG_NO_SPLITK on the call): never split
 void nd_plan_split(long ntiles, int nchunks, long slots, long max_items, int *first, int *S, int *cps) {
-    const SplitPlan sp = plan_split(ntiles, nchunks, slots, g_split_on ? max_items : 0, kSplitOver);
+    const SplitPlan sp = plan_split(ntiles, nchunks, slots, max_items, kSplitOver);
     *first = sp.first;
     *S = sp.S;
     *cps = sp.cps;
@@ -217,7 +212,7 @@ static int pick_variant(const ConvDesc &d, int M) {
                 const long pv = (long)Hv * Wv;
                 const long tn = cross ? ((long)d.in.B * pv + V.nblk - 1) / V.nblk : ((pv + V.nblk - 1) / V.nblk) * d.in.B;
                 const long tiles = tn * ((M + V.mblk - 1) / V.mblk);
-                const long cap = d.part && g_split_on ? (long)(d.part_bytes / ((size_t)V.mblk * V.nblk * 4)) : 0;
+                const long cap = d.part && !d.nosplit ? (long)(d.part_bytes / ((size_t)V.mblk * V.nblk * 4)) : 0;
                 const double cost = plan_split(tiles, KB / V.kbc, cus, cap, kSplitOver).time * V.nblk * c.unit;
                 if (best_v < 0 || cost < best) {
                     best = cost;
@@ -338,7 +333,7 @@ int nd_launch_conv(const ConvDesc &d, hipStream_t stream) {
     const long ntiles = (long)p.tiles_per_problem * (d.nbatch > 1 ? d.nbatch : 1);
     const int per_cu = lds * 2 <= kMaxLds && V.threads <= 256 ? 2 : 1;
     const long slots = (long)g_num_cus * per_cu;
-    const long cap = d.part && g_split_on ? (long)(d.part_bytes / ((size_t)V.mblk * V.nblk * 4)) : 0;
+    const long cap = d.part && !d.nosplit ? (long)(d.part_bytes / ((size_t)V.mblk * V.nblk * 4)) : 0;
     const SplitPlan sp = plan_split(ntiles, KB / V.kbc, slots, cap, kSplitOver);
     p.split_first = sp.first;
     p.S = sp.S;

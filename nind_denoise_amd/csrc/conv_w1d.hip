@@ -473,7 +473,7 @@ int nd_launch_conv_w1d(int T, const ConvDesc &d, hipStream_t stream) {
     p.tiles_per_problem = p.n_tiles_n * p.n_tiles_m;
     const long ntiles = p.tiles_per_problem;
     const long slots = cus[dev];
-    const long cap = d.part ? (long)(d.part_bytes / ((size_t)sh.mblk * T * sh.groups * 4)) : 0;
+    const long cap = d.part && !d.nosplit ? (long)(d.part_bytes / ((size_t)sh.mblk * T * sh.groups * 4)) : 0;
     int first, S, cps;
     nd_plan_split(ntiles, KB, slots, cap, &first, &S, &cps);
     p.split_first = first;

@@ -65,6 +65,7 @@ struct ConvDesc {
     long pre_plane = 0;     // 16-byte elements per plane of `pre`
     float *part = nullptr;  // scratch for the split-K tail (raw accumulators of K slices); null: never split
     size_t part_bytes = 0;
+    bool nosplit = false;   // ND_FLAG_NO_SPLITK of the call: keep every tile whole (bits independent of the launch composition)
     int nbatch = 1;         // independent problems of this shape in one launch (Winograd positions)
     long in_bs = 0, out_bs = 0;   // 16-byte elements between consecutive problems' input / output buffers
     size_t w_bs = 0;        // floats between consecutive problems' packed weights (the bias is shared)
@@ -79,8 +80,10 @@ int nd_conv_variant_gemm(int cin, int cout);   // 1-tap fp32 variant (256- / 128
 size_t nd_wino_packed_floats(int T, int cin, int cout);
 int nd_wino_pack(int T, int kind, int cin, int cout, const float *w, const float *bias, float *packed);
 size_t nd_wino_scratch_bytes(int T, const QpBuf &in, int cin, int cout);
-int nd_launch_conv_wino(int T, const ConvDesc &d, void *scratch, size_t scratch_bytes, hipStream_t s);
-int nd_conv_winograd_enabled();
+// ev2 (optional, profiling): two events, recorded after the input transform pass and after the GEMM launch
+int nd_launch_conv_wino(int T, const ConvDesc &d, void *scratch, size_t scratch_bytes, hipStream_t s, hipEvent_t *ev2 = nullptr);
+// algorithmic HBM bytes of the two transform passes of a three-pass layer (X read + V written; M read + Y written)
+void nd_wino_xform_bytes(int T, const QpBuf &in, int cin, int cout, double *bytes_in, double *bytes_out);
 // 1-D Winograd F(2,3) along x inside the implicit-GEMM kernel (conv_w1d.hip): fp32 inference form of the narrow 3x3 layers
 // (T = 2: F(2,3), 2/3 of the MFMAs;  T = 4: F(4,3), 1/2)
 size_t nd_w1d_packed_floats(int T, int cin, int cout);

@@ -134,37 +134,43 @@ static int forward_common(int funit, int act, int dtype, const void *packed, int
     return ND_OK;
 }
 
-extern "C" int nd_utnet_forward_hw(int funit, int act, int dtype, const void *packed, const float *x, float *y, int batch,
-                                   int h, int w, void *ws, size_t ws_bytes, void *stream);
-extern "C" int nd_utnet_forward(int funit, int act, int dtype, const void *packed, const float *x, float *y, int batch,
-                                int cs, void *ws, size_t ws_bytes, void *stream) {
-    return nd_utnet_forward_hw(funit, act, dtype, packed, x, y, batch, cs, cs, ws, ws_bytes, stream);
+static int check_flags(int flags) {
+    if (flags & ~(ND_FLAG_NO_SPLITK | ND_FLAG_DIRECT_CONV)) ND_FAIL(ND_EINVAL, "unknown flag bits 0x%x", flags);
+    return ND_OK;
 }
-extern "C" int nd_utnet_forward_hw(int funit, int act, int dtype, const void *packed, const float *x, float *y, int batch,
-                                   int h, int w, void *ws, size_t ws_bytes, void *stream) {
+extern "C" int nd_utnet_forward_hw(int funit, int act, int dtype, int flags, const void *packed, const float *x, float *y,
+                                   int batch, int h, int w, void *ws, size_t ws_bytes, void *stream);
+extern "C" int nd_utnet_forward(int funit, int act, int dtype, int flags, const void *packed, const float *x, float *y,
+                                int batch, int cs, void *ws, size_t ws_bytes, void *stream) {
+    return nd_utnet_forward_hw(funit, act, dtype, flags, packed, x, y, batch, cs, cs, ws, ws_bytes, stream);
+}
+extern "C" int nd_utnet_forward_hw(int funit, int act, int dtype, int flags, const void *packed, const float *x, float *y,
+                                   int batch, int h, int w, void *ws, size_t ws_bytes, void *stream) {
+    ND_TRY(check_flags(flags));
     Plan pl;
     ND_TRY(forward_common(funit, act, dtype, packed, batch, batch, h, w, ws, ws_bytes, &pl));
     if (!x || !y) ND_FAIL(ND_EINVAL, "UtNet: null tensor");
     hipStream_t s = (hipStream_t)stream;
     const float *blob = (const float *)packed;
     ND_TRY(nd_launch_reflect_pack(x, batch, h, w, pl.buf[X0], s));
-    ND_TRY(run_stack(funit, act, dtype, blob, pl, s));
+    ND_TRY(run_stack(funit, act, dtype, blob, pl, s, flags));
     const BlobLayout bl = blob_layout(funit, dtype);
     const float *fw = blob + bl.off[kNumLayers - 1];
     ND_TRY(nd_launch_final1x1(pl.buf[T4B], funit, fw, fw + 3 * funit, 2, y, h, w, s));
     return ND_OK;
 }
 
-extern "C" int nd_utnet_denoise_tiles(int funit, int act, int dtype, const void *packed, const float *img, float *canvas,
-                                      int width, int height, int cs, int ucs, int ol, int tile_begin, int tile_count,
-                                      int batch, void *ws, size_t ws_bytes, void *stream) {
+extern "C" int nd_utnet_denoise_tiles(int funit, int act, int dtype, int flags, const void *packed, const float *img,
+                                      float *canvas, int width, int height, int cs, int ucs, int ol, int tile_begin,
+                                      int tile_count, int batch, void *ws, size_t ws_bytes, void *stream) {
+    ND_TRY(check_flags(flags));
     Plan pl;
     ND_TRY(forward_common(funit, act, dtype, packed, batch, tile_count, cs, cs, ws, ws_bytes, &pl));
     if (!img || !canvas) ND_FAIL(ND_EINVAL, "UtNet: null image");
     hipStream_t s = (hipStream_t)stream;
     const float *blob = (const float *)packed;
     ND_TRY(nd_launch_gather_pack(img, width, height, cs, ucs, ol, tile_begin, tile_count, pl.buf[X0], s));
-    ND_TRY(run_stack(funit, act, dtype, blob, pl, s));
+    ND_TRY(run_stack(funit, act, dtype, blob, pl, s, flags));
     const BlobLayout bl = blob_layout(funit, dtype);
     const float *fw = blob + bl.off[kNumLayers - 1];
     ND_TRY(nd_launch_final1x1_stitch(pl.buf[T4B], funit, fw, fw + 3 * funit, 2, canvas, width, height, cs, ucs, ol,
@@ -172,19 +178,21 @@ extern "C" int nd_utnet_denoise_tiles(int funit, int act, int dtype, const void 
     return ND_OK;
 }
 
-// Profiling entry point (bench.py roofline leg): one forward of the conv stack with a HIP event between every launch
-// on `stream`.  Synchronises the stream.  step_ms[i] = duration of launch i (26 entries: 22 MFMA conv launches and
-// 4 pools, forward order); step_flops[i] = algorithmic FLOP of that launch (0 for pools), SURVEY.md 2a convention.
-extern "C" int nd_utnet_profile_stack(int funit, int act, int dtype, const void *packed, int batch, int cs, void *ws,
-                                      size_t ws_bytes, void *stream, float *step_ms, double *step_flops, int *is_conv,
-                                      int max_steps) {
+// Profiling entry point (bench.py roofline leg): one forward of the conv stack with a HIP event between every launch on
+// `stream` (and around the GEMM launch of a three-pass Winograd layer).  Synchronises the stream.  26 entries, forward order:
+// 22 MFMA conv layers and 4 pools.  FLOP conventions: `flops` = algorithmic (torch FlopCounterMode, no
+// padding-zero MACs); `mfma_flops` = what the matrix cores execute in the form the layer ran in (MFMAs issued x 4096).
+extern "C" int nd_utnet_profile_stack(int funit, int act, int dtype, int flags, const void *packed, int batch, int cs, void *ws,
+                                      size_t ws_bytes, void *stream, nd_step_profile *steps, int max_steps) {
+    ND_TRY(check_flags(flags));
     Plan pl;
     ND_TRY(forward_common(funit, act, dtype, packed, batch, batch, cs, cs, ws, ws_bytes, &pl));
-    if (max_steps < kNumSteps || !step_ms) ND_FAIL(ND_EINVAL, "nd_utnet_profile_stack: need room for %d steps", kNumSteps);
+    if (max_steps < kNumSteps || !steps) ND_FAIL(ND_EINVAL, "nd_utnet_profile_stack: need room for %d steps", kNumSteps);
     hipStream_t s = (hipStream_t)stream;
-    hipEvent_t ev[kNumSteps + 1];
+    hipEvent_t ev[kNumSteps + 1], evx[2 * kNumSteps];
     for (auto &e : ev) ND_HIP(hipEventCreate(&e));
-    int rc = run_stack(funit, act, dtype, (const float *)packed, pl, s, ev);
+    for (auto &e : evx) ND_HIP(hipEventCreate(&e));
+    int rc = run_stack(funit, act, dtype, (const float *)packed, pl, s, flags, ev, nullptr, nullptr, nullptr, evx);
     if (rc == ND_OK) {
         hipError_t e = hipStreamSynchronize(s);
         if (e != hipSuccess) {
@@ -192,30 +200,63 @@ extern "C" int nd_utnet_profile_stack(int funit, int act, int dtype, const void 
             rc = ND_EHIP;
         }
     }
+    const BlobLayout bl = blob_layout(funit, dtype);
     for (int i = 0; i < kNumSteps && rc == ND_OK; ++i) {
-        if (hipEventElapsedTime(&step_ms[i], ev[i], ev[i + 1]) != hipSuccess) {
+        nd_step_profile &o = steps[i];
+        memset(&o, 0, sizeof(o));
+        if (hipEventElapsedTime(&o.ms, ev[i], ev[i + 1]) != hipSuccess) {
             nd_set_error("hipEventElapsedTime failed");
             rc = ND_EHIP;
+            break;
         }
         const Step &st = kSteps[i];
-        double fl = 0;
-        if (st.layer >= 0) {
-            const LayerSpec &l = kLayers[st.layer];
-            const QpBuf &in = pl.buf[st.src];
-            const double ci = lcin(l, funit), co = lcout(l, funit);
-            const double hin = in.Hb - 2 * in.pad, win = in.Wb - 2 * in.pad;
-            switch (l.kind) {
-                case ND_CONV3: fl = 2.0 * (hin - 2) * (win - 2) * ci * co * 9; break;
-                case ND_CONVT3: fl = 2.0 * hin * win * ci * co * 9; break;
-                case ND_CONVT2S2: fl = 2.0 * hin * win * ci * co * 4; break;
-                default: fl = 2.0 * hin * win * ci * co; break;
-            }
-            fl *= batch;
+        const Form form = step_form(st, funit, dtype, flags, pl, bl, false, nullptr);
+        o.form = (int)form;
+        o.kind = st.layer >= 0 ? kLayers[st.layer].kind : -1;
+        const QpBuf &in = pl.buf[st.src], &out = pl.buf[st.dst];
+        const double B = batch, esz = 16.0 / nd_cpp(dtype);      // bytes per stored channel value
+        const double hin = in.Hb - 2 * in.pad, win = in.Wb - 2 * in.pad;
+        if (st.layer < 0) {
+            const double c = st.dst_plane0_mul * funit;
+            o.bytes = B * c * esz * (hin * win + (hin / 2) * (win / 2));
+            continue;
         }
-        if (step_flops) step_flops[i] = fl;
-        if (is_conv) is_conv[i] = st.layer >= 0;
+        const LayerSpec &l = kLayers[st.layer];
+        const double ci = lcin(l, funit), co = lcout(l, funit);
+        const double cip = nd_kblocks((int)ci, dtype) * 2.0 * nd_cpp(dtype);   // input channels padded to whole K blocks
+        double hout, wout;
+        switch (l.kind) {
+            case ND_CONV3: hout = hin - 2; wout = win - 2; o.flops = 2.0 * hout * wout * ci * co * 9; break;
+            case ND_CONVT3: hout = hin + 2; wout = win + 2; o.flops = 2.0 * hin * win * ci * co * 9; break;
+            case ND_CONVT2S2: hout = 2 * hin; wout = 2 * win; o.flops = 2.0 * hin * win * ci * co * 4; break;
+            default: hout = hin; wout = win; o.flops = 2.0 * hin * win * ci * co; break;
+        }
+        o.flops *= B;
+        o.bytes = B * esz * (ci * hin * win + co * hout * wout) + 4.0 * ci * co * nd_taps(l.kind);
+        auto cdiv = [](double a, double b) { return (double)(long)((a + b - 1) / b); };
+        switch (form) {
+            case FORM_W1D4: o.mfma_flops = 2.0 * 3 * 6 * cip * co * hout * cdiv(wout, 4) * B; break;
+            case FORM_W1D2: o.mfma_flops = 2.0 * 3 * 4 * cip * co * hout * cdiv(wout, 2) * B; break;
+            case FORM_WINO3P: o.mfma_flops = 2.0 * 36 * cip * co * cdiv(hout, 4) * cdiv(wout, 4) * B; break;
+            default:
+                o.mfma_flops = l.kind == ND_CONVT2S2 ? 2.0 * 4 * cip * co * hin * win * B
+                                                     : 2.0 * nd_taps(l.kind) * cip * co * hout * wout * B;   // (zero-border MACs of a transposed layer included)
+                break;
+        }
+        if (form == FORM_WINO3P && batch <= kWinoChunk) {
+            float a = 0, b = 0, c = 0;
+            if (hipEventElapsedTime(&a, ev[i], evx[2 * i]) == hipSuccess && hipEventElapsedTime(&b, evx[2 * i], evx[2 * i + 1]) == hipSuccess &&
+                hipEventElapsedTime(&c, evx[2 * i + 1], ev[i + 1]) == hipSuccess) {
+                o.ms_xform_in = a;
+                o.ms_gemm = b;
+                o.ms_xform_out = c;
+            }
+            QpBuf v = in;
+            nd_wino_xform_bytes(kWinoTile, v, (int)ci, (int)co, &o.xform_bytes_in, &o.xform_bytes_out);
+        }
     }
     for (auto &e : ev) (void)hipEventDestroy(e);
+    for (auto &e : evx) (void)hipEventDestroy(e);
     return rc;
 }
 
@@ -301,8 +342,9 @@ extern "C" size_t nd_layer_workspace_bytes(int kind, int batch, int cin, int cou
 }
 
 extern "C" int nd_layer_forward(int kind, int act, float slope, int dtype, const void *packed, const float *x, int batch,
-                                int cin, int h, int w, int cout, float *y, void *ws, size_t ws_bytes, int variant,
+                                int cin, int h, int w, int cout, float *y, void *ws, size_t ws_bytes, int variant, int flags,
                                 void *stream) {
+    ND_TRY(check_flags(flags));
     if (dtype < ND_F32 || dtype > ND_F16) ND_FAIL(ND_EINVAL, "nd_layer_forward: unsupported dtype %d", dtype);
     const size_t need = nd_layer_workspace_bytes(kind, batch, cin, cout, h, w, dtype);
     if (!need) ND_FAIL(ND_EINVAL, "nd_layer_forward: bad shape");
@@ -327,6 +369,7 @@ extern "C" int nd_layer_forward(int kind, int act, float slope, int dtype, const
     d.variant = variant;
     d.part = pl.split;
     d.part_bytes = kSplitScratchBytes;
+    d.nosplit = (flags & ND_FLAG_NO_SPLITK) != 0;
     ND_TRY(nd_launch_conv(d, s));
     ND_TRY(nd_launch_qp_to_nchw(pl.out, 0, y, cout, s));
     return ND_OK;
@@ -356,7 +399,9 @@ extern "C" size_t nd_layer_winograd_workspace_bytes(int tile, int kind, int batc
     return base + nd_wino_scratch_bytes(tile, pl.in, cin, cout);
 }
 extern "C" int nd_layer_forward_winograd(int tile, int kind, int act, float slope, const void *packed, const float *x, int batch,
-                                         int cin, int h, int w, int cout, float *y, void *ws, size_t ws_bytes, void *stream) {
+                                         int cin, int h, int w, int cout, float *y, void *ws, size_t ws_bytes, int flags,
+                                         void *stream) {
+    ND_TRY(check_flags(flags));
     const size_t need = nd_layer_winograd_workspace_bytes(tile, kind, batch, cin, cout, h, w);
     if (!need) ND_FAIL(ND_EINVAL, "nd_layer_forward_winograd: bad shape / kind / tile");
     if (!ws || ws_bytes < need) ND_FAIL(ND_ENOMEM, "nd_layer_forward_winograd: workspace %zu B given, %zu B needed", ws_bytes, need);
@@ -379,6 +424,7 @@ extern "C" int nd_layer_forward_winograd(int tile, int kind, int act, float slop
     d.variant = -1;
     d.part = pl.split;
     d.part_bytes = kSplitScratchBytes;
+    d.nosplit = (flags & ND_FLAG_NO_SPLITK) != 0;
     if (tile & 1) {
         d.bias = d.wpk + (size_t)nd_mtiles(ND_CONV3, cout) * nd_kblocks(cin) * 3 * (tile + 3) * 256;
         ND_TRY(nd_launch_conv_w1d(tile + 1, d, s));

@@ -242,17 +242,37 @@ Plan make_plan(int f, int ch_, int cw_, int cap, int nimg, char *base, int dt) {
     return p;
 }
 
-// ev (optional): kNumSteps+1 events, ev[i] recorded before step i, ev[kNumSteps] after the last one
+// which kernel family runs step `st` of the stack (pl = the plan of the call: the fused 1-D form needs the row's LDS images to fit)
+enum Form { FORM_POOL = -1, FORM_DIRECT = 0, FORM_W1D4 = 1, FORM_W1D2 = 2, FORM_WINO3P = 3 };
+inline Form step_form(const Step &st, int f, int dt, int flags, const Plan &pl, const BlobLayout &bl, bool train,
+                      const unsigned char *train_w1) {
+    if (st.layer < 0) return FORM_POOL;
+    const LayerSpec &l = kLayers[st.layer];
+    if (l.kind != ND_CONV3 && l.kind != ND_CONVT3) return FORM_DIRECT;
+    if (train) return (train_w1 && train_w1[st.layer]) ? FORM_W1D4 : FORM_DIRECT;
+    if (flags & ND_FLAG_DIRECT_CONV) return FORM_DIRECT;
+    if (bl.w1off[st.layer]) {
+        if (nd_w1d_fits(kW1dTile, pl.buf[st.src])) return FORM_W1D4;
+        if (nd_w1d_fits(2, pl.buf[st.src])) return FORM_W1D2;
+        return FORM_DIRECT;
+    }
+    return bl.woff[st.layer] ? FORM_WINO3P : FORM_DIRECT;
+}
+
+// ev (optional): kNumSteps+1 events, ev[i] recorded before step i, ev[kNumSteps] after the last one;
+// ev_x (optional, with ev): 2 events per step, recorded after the input transform and after the GEMMs of a three-pass layer
 // pre (optional, training): kNumSlopes compact buffers that receive acc + bias of every activated layer
 // train_w1 (training forward, with pre): per layer, 1 = the layer's blob region holds the fused 1-D Winograd packing
-int run_stack(int f, int act, int dt, const float *blob, const Plan &pl, hipStream_t s, hipEvent_t *ev = nullptr,
-              const QpBuf *pre = nullptr, const float *slopes = nullptr, const unsigned char *train_w1 = nullptr) {
+// flags: nd_flags of the call (ND_FLAG_NO_SPLITK: every tile whole; ND_FLAG_DIRECT_CONV: no Winograd form on any layer)
+int run_stack(int f, int act, int dt, const float *blob, const Plan &pl, hipStream_t s, int flags = 0, hipEvent_t *ev = nullptr,
+              const QpBuf *pre = nullptr, const float *slopes = nullptr, const unsigned char *train_w1 = nullptr,
+              hipEvent_t *ev_x = nullptr) {
     const BlobLayout bl = blob_layout(f, dt, pre == nullptr, pre != nullptr);
     const int cpp = nd_cpp(dt);
     int si = 0;
     for (const Step &st : kSteps) {
         if (ev) ND_HIP(hipEventRecord(ev[si], s));
-        ++si;
+        const int this_step = si++;
         if (st.layer < 0) {
             // pool reads the skip half of the concat buffer: planes [mul*f/4, 2*mul*f/4)
             ND_TRY(nd_launch_maxpool2(pl.buf[st.src], st.dst_plane0_mul * f / cpp, st.dst_plane0_mul * f / cpp, pl.buf[st.dst], s));
@@ -278,22 +298,17 @@ int run_stack(int f, int act, int dt, const float *blob, const Plan &pl, hipStre
         d.variant = -1;
         d.part = pl.split;
         d.part_bytes = kSplitScratchBytes;
-        if (pre && train_w1 && train_w1[st.layer]) {
-            d.bias = d.wpk + (size_t)nd_mtiles(ND_CONV3, d.cout) * nd_kblocks(d.cin) * 3 * (kW1dTile + 2) * 256;
-            ND_TRY(nd_launch_conv_w1d(kW1dTile, d, s));
+        d.nosplit = (flags & ND_FLAG_NO_SPLITK) != 0;
+        const Form form = step_form(st, f, dt, flags, pl, bl, pre != nullptr, train_w1);
+        if (form == FORM_W1D4 || form == FORM_W1D2) {
+            // narrow layer: 1-D Winograd along x inside the implicit-GEMM kernel; F(4,3), or F(2,3) on rows too wide for it
+            const int T = form == FORM_W1D4 ? kW1dTile : 2;
+            if (!pre) d.wpk = blob + (T == kW1dTile ? bl.w1off[st.layer] : bl.w1off2[st.layer]);
+            d.bias = d.wpk + (size_t)nd_mtiles(ND_CONV3, d.cout) * nd_kblocks(d.cin) * 3 * (T + 2) * 256;
+            ND_TRY(nd_launch_conv_w1d(T, d, s));
             continue;
         }
-        if (!pre && bl.w1off[st.layer] && nd_conv_winograd_enabled()) {
-            // narrow layer: 1-D Winograd along x inside the implicit-GEMM kernel; F(4,3), or F(2,3) on rows too wide for it
-            const int T = nd_w1d_fits(kW1dTile, d.in) ? kW1dTile : (nd_w1d_fits(2, d.in) ? 2 : 0);
-            if (T) {
-                d.wpk = blob + (T == kW1dTile ? bl.w1off[st.layer] : bl.w1off2[st.layer]);
-                d.bias = d.wpk + (size_t)nd_mtiles(ND_CONV3, d.cout) * nd_kblocks(d.cin) * 3 * (T + 2) * 256;
-                ND_TRY(nd_launch_conv_w1d(T, d, s));
-                continue;
-            }
-        }
-        if (!pre && bl.woff[st.layer] && nd_conv_winograd_enabled()) {
+        if (form == FORM_WINO3P) {
             // Winograd form, kWinoChunk images per pass (views of the same buffers)
             d.wpk = blob + bl.woff[st.layer];
             d.bias = nullptr;
@@ -303,7 +318,8 @@ int run_stack(int f, int act, int dt, const float *blob, const Plan &pl, hipStre
                 c.in.B = c.out.B = nimg - b0 < kWinoChunk ? nimg - b0 : kWinoChunk;
                 c.in.base = d.in.base + (size_t)b0 * d.in.Hb * d.in.Wb * 4;
                 c.out.base = d.out.base + (size_t)b0 * d.out.Hb * d.out.Wb * 4;
-                ND_TRY(nd_launch_conv_wino(kWinoTile, c, pl.wino, pl.wino_bytes, s));
+                // (profiling: the split of a layer's time into its passes is recorded for a single-chunk layer only)
+                ND_TRY(nd_launch_conv_wino(kWinoTile, c, pl.wino, pl.wino_bytes, s, (ev_x && nimg <= kWinoChunk) ? ev_x + 2 * this_step : nullptr));
             }
             continue;
         }

@@ -141,6 +141,25 @@ __global__ void k_add_clip_grad(const float *__restrict__ y, const float *__rest
     }
 }
 
+// pt_ops.pt_crop_batch (common/libs/pt_ops.py:1-8; nn_train.py:319-323): centre crop [N,S,S] -> [N,L,L], x0 = y0 = (S - L) / 2
+__global__ void k_center_crop(const float *__restrict__ src, int S, int L, long n_out, float *__restrict__ dst) {
+    const int o = (S - L) / 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_out; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % L), y = (int)((i / L) % L);
+        const long img = i / ((long)L * L);
+        dst[i] = src[(img * S + y + o) * S + x + o];
+    }
+}
+// the gradient on the crop back onto the full output: zero outside the crop
+__global__ void k_center_uncrop(const float *__restrict__ g, int S, int L, long n_full, float *__restrict__ dst) {
+    const int o = (S - L) / 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_full; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % S) - o, y = (int)((i / S) % S) - o;
+        const long img = i / ((long)S * S);
+        dst[i] = (x >= 0 && x < L && y >= 0 && y < L) ? g[(img * L + y) * L + x] : 0.f;
+    }
+}
+
 // data gradient of the final Conv2d(f,3,1) + crop: g[c][b][Y][X] = sum_co gy[co][b][Y-crop][X-crop] * w[co][c] (0 outside)
 __global__ void k_final_bwd_data(const float *__restrict__ gy, int S, const float *__restrict__ w, int cin, int crop,
                                  f32x4 *__restrict__ g, long gnp, int Hb, int Wb, int B) {
@@ -294,6 +313,7 @@ struct TrainPlan {
     float *red;             // reduction scratch
     float *gy;              // d loss / d output  [B,3,S,S]
     float *yclip, *gssim;   // SSIM / MS-SSIM terms: clip(y, 0, 1) and the gradient with respect to it  [B,3,S,S]
+    float *ycrop, *tcrop, *gcrop;   // loss_cs < cs: centre crops of output / target and the gradient on the crop  [B,3,L,L]
     char *ssim_ws;          // nd_ssim_loss_workspace_bytes(B, 3, S, S)
     size_t ssim_ws_bytes;
     size_t bytes;
@@ -384,6 +404,10 @@ TrainPlan make_train_plan(int f, int cs, int B, char *base) {
     off += ((size_t)B * 3 * cs * cs * 4 + 255) & ~(size_t)255;
     t.gssim = (float *)(base ? base + off : nullptr);
     off += ((size_t)B * 3 * cs * cs * 4 + 255) & ~(size_t)255;
+    for (float **pp : {&t.ycrop, &t.tcrop, &t.gcrop}) {
+        *pp = (float *)(base ? base + off : nullptr);
+        off += ((size_t)B * 3 * cs * cs * 4 + 255) & ~(size_t)255;
+    }
     t.ssim_ws = base ? base + off : nullptr;
     t.ssim_ws_bytes = nd_ssim_loss_workspace_bytes(B, 3, cs, cs);
     off += (t.ssim_ws_bytes + 255) & ~(size_t)255;
@@ -443,13 +467,16 @@ extern "C" int nd_utnet_train_workspace_init(void *ws, size_t ws_bytes, int funi
 //          + w_msssim * mean_n(1 - MS-SSIM_n(g, target)),      g = clip(y, 0, 1)          (nn_common.py:198-199, 226-241)
 // and the backward pass.  params / grads: flat fp32 buffers in state-dict order (nd_utnet_param_range);
 // x, target, y_out: [batch,3,cs,cs] NCHW fp32; loss_out: one float in HBM; blobs: nd_utnet_train_blob_bytes scratch.
-extern "C" int nd_utnet_train_step(int funit, const float *params, float *grads, void *blobs, const float *x,
+extern "C" int nd_utnet_train_step(int funit, int flags, const float *params, float *grads, void *blobs, const float *x,
                                    const float *target, float *y_out, float w_l1, float w_mse, float w_ssim, float w_msssim,
-                                   float *loss_out, int batch, int cs, void *ws, size_t ws_bytes, void *stream) {
+                                   float *loss_out, int batch, int cs, int loss_cs, void *ws, size_t ws_bytes, void *stream) {
     ND_TRY(check_train(funit, cs, batch));
-    if (w_msssim != 0.f && cs < 161)
+    const int L = loss_cs > 0 ? loss_cs : cs;   // the criteria see the centre crop of this size (nn_train.py:319-323)
+    if (L > cs) ND_FAIL(ND_EINVAL, "UtNet training: loss_cs=%d exceeds the crop size %d", L, cs);
+    if (w_msssim != 0.f && L < 161)
         ND_FAIL(ND_EINVAL, "UtNet training: the MS-SSIM loss needs crops of at least 161 pixels (five scales of an 11-tap window), "
-                           "got %d; the reference fails on them too (pt_losses.py:20-28)", cs);
+                           "got %d; the reference fails on them too (pt_losses.py:20-28)", L);
+    if (w_ssim != 0.f && L < 11) ND_FAIL(ND_EINVAL, "UtNet training: the SSIM loss needs at least 11 pixels, got %d", L);
     if (!params || !grads || !blobs || !x || !target || !y_out || !loss_out || !ws) ND_FAIL(ND_EINVAL, "train step: null pointer");
     TrainPlan t = make_train_plan(funit, cs, batch, (char *)ws);
     if (ws_bytes < t.bytes) ND_FAIL(ND_ENOMEM, "UtNet training workspace: %zu B given, %zu B needed", ws_bytes, t.bytes);
@@ -463,7 +490,7 @@ extern "C" int nd_utnet_train_step(int funit, const float *params, float *grads,
         if (st.layer < 0) continue;
         const LayerSpec &l = kLayers[st.layer];
         if (l.kind != ND_CONV3 && l.kind != ND_CONVT3) continue;
-        if (nd_conv_winograd_enabled()) {
+        if (!(flags & ND_FLAG_DIRECT_CONV)) {
             fwd_w1[st.layer] = nd_w1d_fits(kW1dTile, t.fwd.buf[st.src]);
             bwd_w1[st.layer] = st.layer > 0 && nd_w1d_fits(kW1dTile, t.g[st.dst]);
         }
@@ -512,26 +539,39 @@ extern "C" int nd_utnet_train_step(int funit, const float *params, float *grads,
 
     // ---- 2. forward (training mode: pre-activations kept)
     ND_TRY(nd_launch_reflect_pack(x, B, cs, cs, t.fwd.buf[X0], s));
-    ND_TRY(run_stack(f, ND_ACT_PRELU, ND_F32, fblob, t.fwd, s, nullptr, t.pre, nullptr, fwd_w1));
+    ND_TRY(run_stack(f, ND_ACT_PRELU, ND_F32, fblob, t.fwd, s, flags, nullptr, t.pre, nullptr, fwd_w1));
     const float *fw = fblob + bl.off[kNumLayers - 1];
     ND_TRY(nd_launch_final1x1(t.fwd.buf[T4B], f, fw, fw + 3 * f, 2, y_out, cs, cs, s));
 
-    // ---- 3. loss and its gradient
-    const long nout = (long)B * 3 * cs * cs;
+    // ---- 3. loss and its gradient, on the centre crop of loss_cs pixels (the whole output when loss_cs == cs)
+    const long nfull = (long)B * 3 * cs * cs, nout = (long)B * 3 * L * L;
     const int lblocks = 1024;
-    hipLaunchKernelGGL(k_loss_grad, dim3(lblocks), dim3(256), 0, s, (const float *)y_out, target, nout, w_l1, w_mse, t.gy, t.red);
+    const float *yl = y_out, *tl = target;
+    float *gl = t.gy;
+    if (L != cs) {
+        hipLaunchKernelGGL(k_center_crop, dim3(1024), dim3(256), 0, s, (const float *)y_out, cs, L, nout, t.ycrop);
+        hipLaunchKernelGGL(k_center_crop, dim3(1024), dim3(256), 0, s, target, cs, L, nout, t.tcrop);
+        yl = t.ycrop;
+        tl = t.tcrop;
+        gl = t.gcrop;
+    }
+    hipLaunchKernelGGL(k_loss_grad, dim3(lblocks), dim3(256), 0, s, yl, tl, nout, w_l1, w_mse, gl, t.red);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, (const float *)t.red, lblocks, 1.f / (float)nout, loss_out);
     ND_HIP(hipGetLastError());
     if (w_ssim != 0.f || w_msssim != 0.f) {
-        hipLaunchKernelGGL(k_clip01, dim3(1024), dim3(256), 0, s, (const float *)y_out, nout, t.yclip);
+        hipLaunchKernelGGL(k_clip01, dim3(1024), dim3(256), 0, s, yl, nout, t.yclip);
         int acc = 0;
         if (w_ssim != 0.f) {
-            ND_TRY(nd_ssim_loss_grad(t.yclip, target, B, 3, cs, cs, 0, w_ssim, loss_out, t.gssim, acc, t.ssim_ws, t.ssim_ws_bytes, s));
+            ND_TRY(nd_ssim_loss_grad(t.yclip, tl, B, 3, L, L, 0, w_ssim, loss_out, t.gssim, acc, t.ssim_ws, t.ssim_ws_bytes, s));
             acc = 1;
         }
         if (w_msssim != 0.f)
-            ND_TRY(nd_ssim_loss_grad(t.yclip, target, B, 3, cs, cs, 1, w_msssim, loss_out, t.gssim, acc, t.ssim_ws, t.ssim_ws_bytes, s));
-        hipLaunchKernelGGL(k_add_clip_grad, dim3(1024), dim3(256), 0, s, (const float *)y_out, (const float *)t.gssim, nout, t.gy);
+            ND_TRY(nd_ssim_loss_grad(t.yclip, tl, B, 3, L, L, 1, w_msssim, loss_out, t.gssim, acc, t.ssim_ws, t.ssim_ws_bytes, s));
+        hipLaunchKernelGGL(k_add_clip_grad, dim3(1024), dim3(256), 0, s, yl, (const float *)t.gssim, nout, gl);
+        ND_HIP(hipGetLastError());
+    }
+    if (L != cs) {
+        hipLaunchKernelGGL(k_center_uncrop, dim3(1024), dim3(256), 0, s, (const float *)t.gcrop, cs, L, nfull, t.gy);
         ND_HIP(hipGetLastError());
     }
 
@@ -617,6 +657,7 @@ extern "C" int nd_utnet_train_step(int funit, const float *params, float *grads,
             d.variant = -1;
             d.part = t.fwd.split;
             d.part_bytes = kSplitScratchBytes;
+            d.nosplit = (flags & ND_FLAG_NO_SPLITK) != 0;
             if (bwd_w1[st.layer]) {
                 d.bias = d.wpk + (size_t)nd_mtiles(ND_CONV3, ci) * nd_kblocks(co) * 18 * 256;
                 ND_TRY(nd_launch_conv_w1d(kW1dTile, d, s));

@@ -194,15 +194,6 @@ WinoGeo wino_geo(int T, const QpBuf &in, int cin, int cout) {
 }
 }  // namespace
 
-// ------------------------------------------------------------------ switch
-static int g_wino_on = 1;
-int nd_conv_winograd_enabled() { return g_wino_on; }
-extern "C" int nd_conv_winograd_enable(int on) {
-    const int was = g_wino_on;
-    g_wino_on = on ? 1 : 0;
-    return was;
-}
-
 // ------------------------------------------------------------------ packing (host)
 // layout: P x [1-tap packed GEMM weights U_pos (pack.hip layout, zero bias)] + bias[cout rounded up to 4]
 size_t nd_wino_packed_floats(int T, int cin, int cout) {
@@ -261,7 +252,14 @@ size_t nd_wino_scratch_bytes(int T, const QpBuf &in, int cin, int cout) {
 }
 
 // d: the layer as for nd_launch_conv (kind CONV3 / CONVT3, fp32); d.wpk = nd_wino_pack blob.  scratch: nd_wino_scratch_bytes
-int nd_launch_conv_wino(int T, const ConvDesc &d, void *scratch, size_t scratch_bytes, hipStream_t s) {
+void nd_wino_xform_bytes(int T, const QpBuf &in, int cin, int cout, double *bytes_in, double *bytes_out) {
+    const WinoGeo g = wino_geo(T, in, cin, cout);
+    const double P = positions(T), px_in = (double)in.B * in.Hb * in.Wb, px_out = (double)in.B * g.Hv * g.Wv;
+    *bytes_in = 4.0 * cin * px_in + 4.0 * cin * P * (double)g.tiles;
+    *bytes_out = 4.0 * cout * P * (double)g.tiles + 4.0 * cout * px_out;
+}
+
+int nd_launch_conv_wino(int T, const ConvDesc &d, void *scratch, size_t scratch_bytes, hipStream_t s, hipEvent_t *ev2) {
     if (T != 2 && T != 4) ND_FAIL(ND_EINVAL, "winograd: tile must be 2 or 4");
     if ((d.kind != ND_CONV3 && d.kind != ND_CONVT3) || d.in.dt != ND_F32 || d.out.dt != ND_F32)
         ND_FAIL(ND_EINVAL, "winograd: fp32 3x3 layers only");
@@ -283,6 +281,7 @@ int nd_launch_conv_wino(int T, const ConvDesc &d, void *scratch, size_t scratch_
     else
         hipLaunchKernelGGL(k_wino_input<4>, gi, dim3(256), 0, s, x, d.in.np(), d.in.Hb, d.in.Wb, d.in.B, g.TY, g.TX, v, g.vnp, g.vbs);
     ND_HIP(hipGetLastError());
+    if (ev2) ND_HIP(hipEventRecord(ev2[0], s));
 
     ConvDesc e;
     e.kind = ND_CONV1;
@@ -309,11 +308,13 @@ int nd_launch_conv_wino(int T, const ConvDesc &d, void *scratch, size_t scratch_
     e.variant = nd_conv_variant_gemm(d.cin, d.cout);
     e.part = d.part;
     e.part_bytes = d.part_bytes;
+    e.nosplit = d.nosplit;
     e.nbatch = P;
     e.in_bs = g.vbs;
     e.out_bs = g.mbs;
     e.w_bs = gemm_floats(d.cin, d.cout);
     ND_TRY(nd_launch_conv(e, s));
+    if (ev2) ND_HIP(hipEventRecord(ev2[1], s));
 
     const float *bias = d.wpk + (size_t)P * gemm_floats(d.cin, d.cout);
     dim3 go((unsigned)((g.tiles + 127) / 128), out_planes);

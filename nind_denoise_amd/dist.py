@@ -58,6 +58,23 @@ def _p2p(ops, group):
             w.wait()
 
 
+def _host_staged(group):
+    """gloo moves CPU tensors only: a GPU run over gloo (the two-ranks-on-one-GPU rehearsal of tests / bench.py; RCCL refuses
+    two ranks on one device) stages every message through host memory.  RCCL ("nccl") sends straight from HBM over xGMI."""
+    return dist.get_backend(group) == "gloo"
+
+
+def _wire(t, group):
+    """the tensor that goes on the wire for `t` (contiguous; on the host when the backend needs it)"""
+    t = t.contiguous()
+    return t.cpu() if (t.is_cuda and _host_staged(group)) else t
+
+
+def _landing(shape, like, group):
+    dev = "cpu" if (like.is_cuda and _host_staged(group)) else like.device
+    return torch.empty(shape, dtype=like.dtype, device=dev)
+
+
 def scatter_frame(frame, geo, group=None, src=0):
     """frame: full [3,H,W] buffer on every rank; valid on `src`.  After the call each rank holds the rows it needs."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -70,16 +87,16 @@ def scatter_frame(frame, geo, group=None, src=0):
                 continue
             a, b = geo.rows_in(*geo.shard(r, world))
             if b > a:
-                buf = frame[:, a:b, :].contiguous()
+                buf = _wire(frame[:, a:b, :], group)
                 keep.append(buf)
                 ops.append(dist.P2POp(dist.isend, buf, r, group))
         _p2p(ops, group)
     else:
         a, b = geo.rows_in(*geo.shard(rank, world))
         if b > a:
-            buf = torch.empty((3, b - a, geo.W), dtype=frame.dtype, device=frame.device)
+            buf = _landing((3, b - a, geo.W), frame, group)
             _p2p([dist.P2POp(dist.irecv, buf, src, group)], group)
-            frame[:, a:b, :] = buf
+            frame[:, a:b, :] = buf.to(frame.device)
     return frame
 
 
@@ -95,16 +112,16 @@ def gather_canvas(canvas, geo, group=None, dst=0):
                 continue
             a, b = geo.rows_out(*geo.shard(r, world))
             if b > a:
-                buf = torch.empty((3, b - a, geo.W), dtype=canvas.dtype, device=canvas.device)
+                buf = _landing((3, b - a, geo.W), canvas, group)
                 bufs.append((a, b, buf))
                 ops.append(dist.P2POp(dist.irecv, buf, r, group))
         _p2p(ops, group)
         for a, b, buf in bufs:
-            canvas[:, a:b, :] += buf
+            canvas[:, a:b, :] += buf.to(canvas.device)
     else:
         a, b = geo.rows_out(*geo.shard(rank, world))
         if b > a:
-            _p2p([dist.P2POp(dist.isend, canvas[:, a:b, :].contiguous(), dst, group)], group)
+            _p2p([dist.P2POp(dist.isend, _wire(canvas[:, a:b, :], group), dst, group)], group)
     return canvas
 
 
@@ -127,6 +144,39 @@ def denoise_frame_sharded(compute, frame, canvas, geo, group=None, root=0):
     return canvas
 
 
+def frame_shard(n_frames, rank, world):
+    """Frame-level sharding of a multi-frame batch (BASELINE configs[2]: 100 frames over 8 GPUs): frame f goes to rank
+    f % world.  Whole frames are independent, so there is no per-frame exchange at all -- only the one-time weight broadcast."""
+    return list(range(rank, n_frames, world))
+
+
+def denoise_frames_sharded(denoise, frames, group=None, collect=True):
+    """A batch of frames across the ranks of `group`, frame-level sharding.
+
+    frames: list of [3,H,W] tensors (every rank holds, or can produce, the frames it owns: only frames[f] with
+    f % world == rank are touched).  denoise(frame) -> stitched canvas (pipeline.denoise_frame / serve.FrameEngine).
+    Returns {frame index: canvas} for the frames this rank owns; with collect=True rank 0 receives every other rank's
+    canvases too (point-to-point, one message per frame) and returns the full dict -- the serving case, where results
+    leave through one process."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    mine = frame_shard(len(frames), rank, world)
+    out = {f: denoise(frames[f]) for f in mine}
+    if not collect or world == 1:
+        return out
+    if rank == 0:
+        for f in range(len(frames)):
+            src = f % world
+            if src != 0:
+                like = out[mine[0]] if mine else frames[f]
+                buf = _landing(tuple(like.shape), like, group)
+                _p2p([dist.P2POp(dist.irecv, buf, src, group)], group)
+                out[f] = buf.to(like.device)
+    else:
+        for f in mine:
+            _p2p([dist.P2POp(dist.isend, _wire(out[f], group), 0, group)], group)
+    return out
+
+
 def average_gradients(flat, group=None):
     """Data-parallel training (BASELINE config 5): ONE all-reduce of the flat state-dict-order gradient buffer
     (124 MB fp32 for UtNet(64)), then the mean.  No-op without an initialised process group."""
@@ -134,6 +184,11 @@ def average_gradients(flat, group=None):
         return flat
     world = dist.get_world_size(group)
     if world > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if flat.is_cuda and _host_staged(group):
+            h = flat.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            flat.copy_(h)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         flat.div_(world)
     return flat

@@ -29,6 +29,12 @@ def nearest_valid_cs(cs):
 
 
 class UtNet(nn.Module):
+    # per-call arithmetic flags (nd_flags of include/nind_hip.h), overridable per instance:
+    #   split_k = False  -> every output tile whole: a tile's bits do not depend on the batch grouping
+    #   winograd = False -> direct convolution on every 3x3 layer
+    split_k = True
+    winograd = True
+
     def __init__(self, funit=64, activation='PReLU'):
         super().__init__()
         funit = int(funit)
@@ -63,6 +69,7 @@ class UtNet(nn.Module):
         self._workspaces = {}     # (device, h, w, batch, dtype) -> uint8 tensor
         self.max_cached_workspaces = 2
         self.compute_dtype = "f32"   # storage of activations + weights inside the conv stack: "f32" | "bf16" | "f16"
+        self.weights_generation = 0   # bumped by whoever rewrites the parameters through raw pointers (train.UtNetTrainer)
 
     def set_compute_dtype(self, name):
         """"f32": fp32 storage, exact-fp32 MFMA (the reference's arithmetic).  "bf16" / "f16": 16-bit storage of
@@ -76,9 +83,13 @@ class UtNet(nn.Module):
     def _dt(self):
         return _lib.DTYPE[self.compute_dtype]
 
+    @property
+    def flags(self):
+        return (0 if self.split_k else _lib.FLAG_NO_SPLITK) | (0 if self.winograd else _lib.FLAG_DIRECT_CONV)
+
     # ------------------------------------------------------------------ weights
     def _weights_key(self, device):
-        return (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (str(device), self.weights_generation) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def packed_weights(self, device):
         """Packed blob in HBM (re-packed when a parameter changed or moved)."""
@@ -154,7 +165,7 @@ class UtNet(nn.Module):
             blob = self.packed_weights(x.device)
             ws = self.workspace(h, batch, x.device, width=w)
             y = torch.empty_like(x)
-            _lib.check(lib.nd_utnet_forward_hw(self.funit, _lib.ACT[self.activation], self._dt, blob.data_ptr(),
+            _lib.check(lib.nd_utnet_forward_hw(self.funit, _lib.ACT[self.activation], self._dt, self.flags, blob.data_ptr(),
                                                x.data_ptr(), y.data_ptr(), batch, h, w, ws.data_ptr(), ws.numel(),
                                                _lib.stream_ptr(x.device)), "nd_utnet_forward")
         return y

@@ -67,7 +67,7 @@ def denoise_frame(model, img, cs, ucs, ol, batch=16, tile_range=None, canvas=Non
                 progress(n, t0, cnt)
             if fused:
                 _lib.check(lib.nd_utnet_denoise_tiles(model.funit, _lib.ACT[model.activation], _lib.DTYPE[model.compute_dtype],
-                                                      blob.data_ptr(), img.data_ptr(), canvas.data_ptr(), width, height,
+                                                      model.flags, blob.data_ptr(), img.data_ptr(), canvas.data_ptr(), width, height,
                                                       cs, ucs, ol, t0, cnt, batch, ws.data_ptr(), ws.numel(), stream),
                            "nd_utnet_denoise_tiles")
             else:

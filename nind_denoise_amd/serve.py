@@ -90,11 +90,12 @@ class FrameEngine:
         out = slot["pin_out"].numpy()
         return out.copy() if copy else out
 
-    def run(self, frames):
-        """Generator: denoise an iterable of frames, keeping the ring full; yields results in order."""
+    def run(self, frames, copy=True):
+        """Generator: denoise an iterable of frames, keeping the ring full; yields results in order.  copy=False yields views of
+        the pinned output slots (valid until the slot is reused, `slots` frames later)."""
         for f in frames:
             if len(self.inflight) == len(self.slots):
-                yield self.collect()
+                yield self.collect(copy)
             self.submit(f)
         while self.inflight:
-            yield self.collect()
+            yield self.collect(copy)

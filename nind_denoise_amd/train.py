@@ -23,7 +23,7 @@ from .networks.UtNet import UtNet, valid_cs
 
 class UtNetTrainer:
     def __init__(self, model: UtNet, lr=1e-4, beta1=0.75, beta2=0.999, eps=1e-8, amsgrad=True,
-                 weights=None, device=None, process_group=None):
+                 weights=None, device=None, process_group=None, loss_cs=None):
         if model.activation != "PReLU":
             raise NotImplementedError("the HIP training step implements PReLU networks")
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -38,6 +38,7 @@ class UtNetTrainer:
             raise NotImplementedError(f"loss terms {sorted(unknown)} are not available (generator losses: L1, MSE, SSIM, MSSSIM)")
         self.lr, self.betas, self.eps, self.amsgrad = lr, (beta1, beta2), eps, amsgrad
         self.group = process_group
+        self.loss_cs = loss_cs        # centre crop the criteria see (nn_train.py:319-323 --loss_cs); None: the whole crop
         n = self.lib.nd_utnet_param_count(self.funit)
         if n == 0:
             raise ValueError(f"funit={self.funit} is not supported")
@@ -88,11 +89,11 @@ class UtNetTrainer:
         y = torch.empty_like(noisy)
         with torch.cuda.device(self.device):
             ws = self.workspace(cs, batch)
-            _lib.check(self.lib.nd_utnet_train_step(self.funit, self.flat.data_ptr(), self.grads.data_ptr(),
+            _lib.check(self.lib.nd_utnet_train_step(self.funit, self.model.flags, self.flat.data_ptr(), self.grads.data_ptr(),
                                                     self.blobs.data_ptr(), noisy.data_ptr(), clean.data_ptr(), y.data_ptr(),
                                                     float(self.weights.get("L1", 0.0)), float(self.weights.get("MSE", 0.0)),
                                                     float(self.weights.get("SSIM", 0.0)), float(self.weights.get("MSSSIM", 0.0)),
-                                                    self.loss.data_ptr(), batch, cs, ws.data_ptr(), ws.numel(),
+                                                    self.loss.data_ptr(), batch, cs, int(self.loss_cs or 0), ws.data_ptr(), ws.numel(),
                                                     _lib.stream_ptr(self.device)), "nd_utnet_train_step")
         average_gradients(self.grads, self.group)     # RCCL: one flat all-reduce (124 MB for UtNet(64))
         return y, self.loss
@@ -104,6 +105,9 @@ class UtNetTrainer:
                                              self.vmax.data_ptr(), self.flat.numel(), self.lr, self.betas[0], self.betas[1],
                                              self.eps, self.steps, int(self.amsgrad), _lib.stream_ptr(self.device)),
                        "nd_adam_step")
+        # the parameters were rewritten through raw pointers (torch's version counters did not move): the inference blob the
+        # module cached before this step is stale
+        self.model.weights_generation += 1
 
     def learn(self, noisy, clean):
         """One generator update (Generator.denoise_batch + learn of the reference); returns the loss as a float tensor."""

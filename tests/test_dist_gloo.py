@@ -113,3 +113,48 @@ def test_flat_gradient_average_world_3():
     want = np.arange(1000, dtype=np.float32) * 2.0      # mean of 1x, 2x, 3x
     for r in range(3):
         assert np.array_equal(got[r], want)
+
+
+def _frames_worker(rank, world, port, geom, n_frames, outq):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nind_denoise_amd import dist as ndist
+        from oracle import tiler as otiler
+        W, H, cs, ucs, ol = geom
+        # every rank can produce the frames it owns; the others' stay NaN and must never be read
+        frames = [torch.from_numpy(synth.make_frame(W, H, seed=100 + f)) if f % world == rank else torch.full((3, H, W), float("nan"))
+                  for f in range(n_frames)]
+
+        def denoise(fr):
+            return torch.from_numpy(otiler.denoise_frame(fr.numpy(), cs, ucs, ol, _model, batch=4))
+
+        out = ndist.denoise_frames_sharded(denoise, frames)
+        assert sorted(ndist.frame_shard(n_frames, rank, world)) == sorted(f for f in range(n_frames) if f % world == rank)
+        if rank == 0:
+            outq.put({f: c.numpy() for f, c in out.items()})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_frame_level_sharding_world_2():
+    """BASELINE configs[2]'s shape (a batch of frames over the ranks): frames dealt round-robin, no per-frame exchange, results
+    collected on rank 0 -- bit-identical to denoising every frame on one rank."""
+    from oracle import tiler as otiler
+    geom, n_frames, world = (333, 290, 120, 88, 16), 5, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_frames_worker, args=(r, world, port, geom, n_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    W, H, cs, ucs, ol = geom
+    assert sorted(got) == list(range(n_frames))
+    for f in range(n_frames):
+        ref = otiler.denoise_frame(synth.make_frame(W, H, seed=100 + f), cs, ucs, ol, _model, batch=4)
+        assert np.array_equal(got[f], ref)

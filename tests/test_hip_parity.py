@@ -30,13 +30,13 @@ def dev():
 
 
 @pytest.fixture
-def whole_k(dev):
-    """Plumbing tests that compare two groupings of the same tiles bit for bit run with the split-K tail off: with it on, a
-    tile's fp32 sums may be re-associated depending on where the tile sits in its batch (see nd_conv_split_enable)."""
-    lib = _lib.load()
-    was = lib.nd_conv_split_enable(0)
+def whole_k(dev, monkeypatch):
+    """Plumbing tests that compare two groupings of the same tiles bit for bit run with the split-K tail off (the per-call flag
+    ND_FLAG_NO_SPLITK, which UtNet.split_k = False sets): with it on, a tile's fp32 sums may be re-associated depending on
+    where the tile sits in its batch."""
+    from nind_denoise_amd.networks.UtNet import UtNet
+    monkeypatch.setattr(UtNet, "split_k", False)
     yield
-    lib.nd_conv_split_enable(was)
 
 
 def assert_close(y, ref, what=""):
@@ -53,7 +53,7 @@ def assert_close(y, ref, what=""):
 
 # ---------------------------------------------------------------------------- single layers
 
-def layer_forward(dev, kind, x, w, b, act="none", slope=0.25, variant=-1, dtype="f32"):
+def layer_forward(dev, kind, x, w, b, act="none", slope=0.25, variant=-1, dtype="f32", flags=0):
     lib = _lib.load()
     k = _lib.KIND[kind]
     dt = _lib.DTYPE[dtype]
@@ -71,7 +71,7 @@ def layer_forward(dev, kind, x, w, b, act="none", slope=0.25, variant=-1, dtype=
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     xd = x.to(dev).contiguous()
     _lib.check(lib.nd_layer_forward(k, _lib.ACT[act], slope, dt, packed.data_ptr(), xd.data_ptr(), B, cin, H, W,
-                                    cout, y.data_ptr(), ws.data_ptr(), wsb, variant, _lib.stream_ptr(dev)))
+                                    cout, y.data_ptr(), ws.data_ptr(), wsb, variant, flags, _lib.stream_ptr(dev)))
     torch.cuda.synchronize()
     return y
 
@@ -157,13 +157,8 @@ def test_layer_split_k(dev, case, dtype):
     b = rnd((cout,), 3, 0.2)
     if dtype == "bf16":
         x, w = x.to(torch.bfloat16).float(), w.to(torch.bfloat16).float()
-    lib = _lib.load()
     y_on = layer_forward(dev, kind, x, w, b, act, 0.13, dtype=dtype)
-    was = lib.nd_conv_split_enable(0)
-    try:
-        y_off = layer_forward(dev, kind, x, w, b, act, 0.13, dtype=dtype)
-    finally:
-        lib.nd_conv_split_enable(was)
+    y_off = layer_forward(dev, kind, x, w, b, act, 0.13, dtype=dtype, flags=_lib.FLAG_NO_SPLITK)
     ref = ref_layer(kind, x, w, b, act, 0.13)
     if dtype == "f32":
         assert_close(y_on, ref, f"{case} split")
@@ -217,7 +212,7 @@ def test_layer_winograd(dev, case, tile):
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     xd = x.to(dev).contiguous()
     _lib.check(lib.nd_layer_forward_winograd(tile, k, _lib.ACT[act], 0.13, packed.data_ptr(), xd.data_ptr(), B, cin, H, W, cout,
-                                             y.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr(dev)))
+                                             y.data_ptr(), ws.data_ptr(), wsb, 0, _lib.stream_ptr(dev)))
     torch.cuda.synchronize()
     ref = ref_layer(kind, x, w, b, act, 0.13)
     err = assert_close(y, ref, f"winograd F({tile},3) {case}")
@@ -396,30 +391,26 @@ def test_utnet_f64_cs264_golden(dev, golden_dir):
     x = torch.from_numpy(d["x"]).to(dev)
     err = assert_close(net(x), torch.from_numpy(d["y"]), "utnet f64 cs264")
     # run-to-run determinism: the same batch gives the same bits.  Across batch compositions the split-K tail of a launch
-    # (nind_hip.h: nd_conv_split_enable) may re-associate a tile's fp32 sums, so that comparison carries a tolerance;
-    # with the split switched off a tile's bits do not depend on the batch around it
+    # may re-associate a tile's fp32 sums, so that comparison carries a tolerance; with ND_FLAG_NO_SPLITK on the call
+    # (net.split_k = False) a tile's bits do not depend on the batch around it
     xb = torch.cat([x, x.flip(3), x])
     yb = net(xb)
     assert torch.equal(yb, net(xb))
     assert (yb[0] - net(x)[0]).abs().max().item() < 1e-5 and (yb[0] - yb[2]).abs().max().item() < 1e-5
-    lib = _lib.load()
-    was = lib.nd_conv_split_enable(0)
-    try:
-        yb = net(xb)
-        assert torch.equal(yb[0], yb[2]) and torch.equal(yb[0], net(x)[0])
-        assert_close(yb[:1], torch.from_numpy(d["y"]), "utnet f64 cs264, split-K off")
-    finally:
-        lib.nd_conv_split_enable(was)
-    # the default path runs the >= 128-channel 3x3 layers in Winograd F(4x4,3x3) form (nd_conv_winograd_enable); the direct
-    # form of every layer must meet the same bar, and the two agree far inside it
+    net.split_k = False
+    yb = net(xb)
+    assert torch.equal(yb[0], yb[2]) and torch.equal(yb[0], net(x)[0])
+    assert_close(yb[:1], torch.from_numpy(d["y"]), "utnet f64 cs264, split-K off")
+    net.split_k = True
+    # the default path runs the >= 128-channel 3x3 layers in Winograd F(4x4,3x3) form and the narrower ones in the fused 1-D
+    # form; the direct form of every layer (ND_FLAG_DIRECT_CONV) must meet the same bar, and the two agree far inside it
     y_w = net(x)
-    was = lib.nd_conv_winograd_enable(0)
-    try:
-        y_d = net(x)
-        err_d = assert_close(y_d, torch.from_numpy(d["y"]), "utnet f64 cs264, direct convolution everywhere")
-    finally:
-        lib.nd_conv_winograd_enable(was)
-    assert was == 1 and (y_w - y_d).abs().max().item() < 1e-5
+    assert net.winograd and net.flags == 0
+    net.winograd = False
+    y_d = net(x)
+    err_d = assert_close(y_d, torch.from_numpy(d["y"]), "utnet f64 cs264, direct convolution everywhere")
+    net.winograd = True
+    assert (y_w - y_d).abs().max().item() < 1e-5 and not torch.equal(y_w, y_d)
     print(f"utnet f64 cs264 direct-only max abs err {err_d:.3e}, winograd vs direct {(y_w - y_d).abs().max().item():.3e}")
     print(f"utnet f64 cs264 max abs err {err:.3e}")
 
@@ -520,7 +511,7 @@ def test_frame_end_to_end_vs_oracle(dev, whole_k):
     out3 = pipeline.denoise_frame(net, img, cs, ucs, ol, batch=3)
     assert torch.equal(out, out3)
     # split-K tail on (the default): same frame up to fp32 re-association of a few tiles' sums
-    _lib.load().nd_conv_split_enable(1)
+    net.split_k = True
     out4 = pipeline.denoise_frame(net, img, cs, ucs, ol, batch=5)
     assert_close(out4, torch.from_numpy(ref), "frame e2e, split-K on")
     assert (out4 - out).abs().max().item() < 1e-5
@@ -575,10 +566,12 @@ def test_utnet_f64_wide_tiles_vs_oracle(dev, cs):
         ref = onet.utnet_forward(sd, x)
     assert_close(net(x.to(dev)), ref, f"f64 cs{cs}")
     # BASELINE configs 3 / 4 at these tile sizes: 16-bit storage, fp32 accumulate (1e-3 applies to fp32 only -> PSNR bars)
-    for dtype, min_psnr in (("f16", 55.0), ("bf16", 38.0)):
+    # (bars a few dB under the measured values: 89.7 dB fp16 / 70.6 dB bf16 at cs = 264, peak = the reference's range)
+    for dtype, min_psnr in (("f16", 85.0), ("bf16", 65.0)):
         y = net.set_compute_dtype(dtype)(x.to(dev)).float().cpu()
         mse = ((y - ref) ** 2).mean().item()
-        psnr = 10 * np.log10(max(ref.abs().max().item(), 1e-12) ** 2 / max(mse, 1e-30))
+        psnr = 10 * np.log10((ref.max() - ref.min()).item() ** 2 / max(mse, 1e-30))
+        print(f"UtNet(64) cs={cs} {dtype}: PSNR {psnr:.1f} dB, max abs err {(y - ref).abs().max().item():.3e}")
         assert torch.isfinite(y).all() and psnr >= min_psnr, (dtype, cs, psnr)
     net.set_compute_dtype("f32")
 
@@ -673,7 +666,7 @@ def test_half_layers_exact_on_integer_data(dev, dtype):
     assert torch.equal(y.cpu(), F.conv2d(x3, w3, b).to(tdt).float())
 
 
-@pytest.mark.parametrize("dtype,min_psnr", [("bf16", 38.0), ("f16", 55.0)])
+@pytest.mark.parametrize("dtype,min_psnr", [("bf16", 65.0), ("f16", 85.0)])   # measured 70.6 / 89.7 dB
 def test_utnet_half_storage_vs_fp32_oracle(dev, golden_dir, dtype, min_psnr):
     # configs 3 / 4: 16-bit storage, fp32 accumulate.  The 1e-3 bar is for fp32 only; here parity is reported as
     # max-abs and PSNR against the fp32 reference output (peak = the reference's own range)
@@ -710,7 +703,7 @@ def test_frame_half_storage_fused_equals_unfused(dev, dtype, whole_k):
     net.set_compute_dtype("f32")
     c = pipeline.denoise_frame(net, img, 120, 88, 16, batch=5)
     rel = ((a - c).abs().max() / c.abs().max()).item()
-    assert rel < (0.05 if dtype == "bf16" else 0.01), rel
+    assert rel < (0.01 if dtype == "bf16" else 0.002), rel
 
 
 def test_frame_engine_streams_frames_in_order(dev):
@@ -789,15 +782,18 @@ def test_api_error_paths(dev):
     ws = torch.empty(1 << 20, dtype=torch.uint8, device=dev)
     blob = torch.zeros(1 << 10, device=dev)
     x = torch.zeros(1, 3, 104, 104, device=dev)
-    rc = lib.nd_utnet_forward(16, 1, 0, blob.data_ptr(), x.data_ptr(), x.data_ptr(), 1, 104, ws.data_ptr(), ws.numel(),
+    rc = lib.nd_utnet_forward(16, 1, 0, 0, blob.data_ptr(), x.data_ptr(), x.data_ptr(), 1, 104, ws.data_ptr(), ws.numel(),
                               _lib.stream_ptr(dev))
     assert rc == -2 and b"workspace" in lib.nd_last_error()      # ND_ENOMEM: workspace too small, nothing launched
-    rc = lib.nd_utnet_forward(12, 1, 0, blob.data_ptr(), x.data_ptr(), x.data_ptr(), 1, 104, ws.data_ptr(), ws.numel(),
+    rc = lib.nd_utnet_forward(12, 1, 0, 0, blob.data_ptr(), x.data_ptr(), x.data_ptr(), 1, 104, ws.data_ptr(), ws.numel(),
                               _lib.stream_ptr(dev))
     assert rc == -1                                              # funit not a multiple of 8
-    rc = lib.nd_utnet_forward(16, 7, 0, blob.data_ptr(), x.data_ptr(), x.data_ptr(), 1, 104, ws.data_ptr(), ws.numel(),
+    rc = lib.nd_utnet_forward(16, 7, 0, 0, blob.data_ptr(), x.data_ptr(), x.data_ptr(), 1, 104, ws.data_ptr(), ws.numel(),
                               _lib.stream_ptr(dev))
     assert rc == -1                                              # unknown activation
+    rc = lib.nd_utnet_forward(16, 1, 0, 64, blob.data_ptr(), x.data_ptr(), x.data_ptr(), 1, 104, ws.data_ptr(), ws.numel(),
+                              _lib.stream_ptr(dev))
+    assert rc == -1 and b"flag" in lib.nd_last_error()           # unknown flag bit
     assert lib.nd_utnet_workspace_bytes(16, 104, 1, 1) > 0 and lib.nd_utnet_workspace_bytes(8, 104, 1, 1) == 0   # bf16 needs funit%16
     torch.cuda.synchronize()
 
@@ -880,13 +876,16 @@ def test_weight_gradient_vs_autograd(dev, case):
         assert err <= 2e-5 * max(ref.abs().max().item(), 1.0) + 1e-5, (case, what, err, ref.abs().max().item())
 
 
-def _autograd_reference(sd, x, t, w_l1, w_mse, dtype=torch.float32, w_ssim=0.0, w_msssim=0.0):
+def _autograd_reference(sd, x, t, w_l1, w_mse, dtype=torch.float32, w_ssim=0.0, w_msssim=0.0, loss_cs=None):
     from oracle import losses as olosses
     from oracle import networks as onet
     params = {k: v.clone().to(dtype).requires_grad_() for k, v in sd.items()}
     x, t = x.to(dtype), t.to(dtype)
     y = onet.utnet_forward(params, x)
     g = y.clip(0, 1)
+    if loss_cs is not None:     # pt_ops.pt_crop_batch (nn_train.py:319-323): the criteria see the centre crop only
+        o = (g.shape[2] - loss_cs) // 2
+        g, t = g[:, :, o:o + loss_cs, o:o + loss_cs], t[:, :, o:o + loss_cs, o:o + loss_cs]
     loss = w_l1 * F.l1_loss(g, t) + w_mse * F.mse_loss(g, t)
     if w_ssim:
         loss = loss + w_ssim * (1 - olosses.ssim(g, t)).mean()
@@ -927,7 +926,9 @@ def test_training_step_gradients_vs_autograd(dev, funit, cs, B, w_l1, w_mse):
         scale = max(ref.abs().max().item(), 1e-8)
         err = (got - ref).abs().max().item() / scale
         worst = max(worst, err)
-        bar = 2e-3 + (10 * (params32[name].grad - ref).abs().max().item() / scale if wide else 0.0)
+        # fixed bars, ~3x / ~1.5x what was measured (narrow nets vs fp32 autograd: 8e-6 .. 9.4e-5 with the fused 1-D Winograd
+        # kernel in the forward and data-gradient passes; funit 64 vs float64: 3.5e-3)
+        bar = 5e-3 if wide else 3e-4
         assert torch.isfinite(got).all() and err <= bar, (name, err, bar, scale)
     print(f"training step f{funit} cs{cs}: worst relative gradient error {worst:.2e}")
 
@@ -978,10 +979,11 @@ def test_training_step_ssim_losses_vs_autograd(dev, cs, weights):
         scale = max(ref.abs().max().item(), 1e-8)
         err = (got - ref).abs().max().item() / scale
         worst = max(worst, err)
-        # reference = float64 autograd; bar tied to what fp32 autograd itself loses on the same tensor: the SSIM gradient
-        # oscillates in sign from pixel to pixel, so whole-image sums (PReLU slopes, biases) keep few digits in fp32
-        bar = 2e-3 + 10 * (params32[name].grad - ref).abs().max().item() / scale
-        assert torch.isfinite(got).all() and err <= bar, (name, err, bar, scale)
+        # reference = float64 autograd, fixed bars at ~2x what was measured (mixed loss 7e-4, MS-SSIM alone 7.5e-3: the SSIM
+        # gradient oscillates in sign from pixel to pixel, so whole-image sums -- PReLU slopes, biases -- keep few digits in
+        # fp32; fp32 autograd itself is params32 away from float64 on the same tensors)
+        bar = 1.5e-2 if set(weights) == {"MSSSIM"} else 2e-3
+        assert torch.isfinite(got).all() and err <= bar, (name, err, bar, scale, (params32[name].grad - ref).abs().max().item() / scale)
     print(f"training step {weights} cs{cs}: worst relative gradient error {worst:.2e}")
     if "MSSSIM" in weights:
         with pytest.raises(ValueError, match="161"):     # the 128 / 136-pixel crops of BASELINE config 5 cannot use MS-SSIM
@@ -1016,3 +1018,217 @@ def test_adam_amsgrad_two_steps_vs_torch(dev):
         upd_ref = (p.detach() - sd[name]).abs().max().item()
         err = (new[name].detach().cpu() - p.detach()).abs().max().item()
         assert err <= 0.05 * max(upd_ref, 1e-6) + 2e-6, (name, err, upd_ref)
+
+
+def test_forward_after_optimizer_step_uses_new_weights(dev):
+    # nd_adam_step rewrites the parameters through raw pointers (torch's version counters do not move): the inference blob the
+    # module packed before the step must not be reused (validation between epochs, nn_train.py, runs the same model object)
+    from nind_denoise_amd.networks.UtNet import UtNet
+    from nind_denoise_amd.train import UtNetTrainer
+    from oracle import networks as onet
+    funit, cs, B = 8, 104, 2
+    sd = synth.make_utnet_state_dict(funit=funit, seed=5, gain=1.8)
+    net = UtNet(funit=funit)
+    net.load_state_dict(sd)
+    tr = UtNetTrainer(net, lr=1e-2, beta1=0.75, device=dev, weights={"L1": 1.0, "MSE": 0.0})
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(B, 3, cs, cs, generator=g)
+    t = torch.rand(B, 3, cs, cs, generator=g)
+    y_before = tr.model(x.to(dev)).clone()          # primes the packed-weights cache
+    tr.learn(x, t)
+    y_after = tr.model(x.to(dev))
+    new_sd = {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()}
+    with torch.no_grad():
+        ref = onet.utnet_forward(new_sd, x)
+    assert_close(y_after, ref, "forward after learn()")
+    assert (y_after - y_before).abs().max().item() > 1e-4       # the step really moved the output
+
+
+@pytest.mark.parametrize("weights,cs,loss_cs", [({"L1": 0.5, "MSE": 0.5}, 120, 88), ({"SSIM": 1.0}, 136, 101),
+                                                ({"MSE": 1.0}, 104, 104)])
+def test_training_step_loss_center_crop(dev, weights, cs, loss_cs):
+    # nn_train.py:319-323 computes the loss on pt_crop_batch(., loss_cs) (train_conf_defaults.yaml: loss_cs 161 < cs): the
+    # gradient with respect to the output is zero outside the centre crop
+    from nind_denoise_amd.networks.UtNet import UtNet
+    from nind_denoise_amd.train import UtNetTrainer
+    funit, B = 8, 2
+    sd = synth.make_utnet_state_dict(funit=funit, seed=19, gain=1.8)
+    net = UtNet(funit=funit)
+    net.load_state_dict(sd)
+    tr = UtNetTrainer(net, device=dev, weights=weights, loss_cs=loss_cs)
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(B, 3, cs, cs, generator=g)
+    t = (x * 0.9 + 0.05 * torch.rand(B, 3, cs, cs, generator=g)).clip(0, 1)
+    y, loss = tr.forward_backward(x, t)
+    torch.cuda.synchronize()
+    kw = dict(w_ssim=weights.get("SSIM", 0.0), w_msssim=weights.get("MSSSIM", 0.0), loss_cs=loss_cs)
+    y_ref, loss_ref, params = _autograd_reference(sd, x, t, weights.get("L1", 0.0), weights.get("MSE", 0.0), torch.float64, **kw)
+    assert_close(y, y_ref.float(), "training forward")
+    assert abs(loss.item() - loss_ref.item()) <= 2e-5 * max(1.0, abs(loss_ref.item())), (loss.item(), loss_ref.item())
+    for name, p in params.items():
+        got, ref = tr.grad_of(name).cpu(), p.grad.float()
+        scale = max(ref.abs().max().item(), 1e-8)
+        err = (got - ref).abs().max().item() / scale
+        assert torch.isfinite(got).all() and err <= 2e-3, (name, err, scale)
+    with pytest.raises(ValueError):
+        UtNetTrainer(net, device=dev, weights=weights, loss_cs=cs + 8).forward_backward(x, t)
+
+
+# ---------------------------------------------------------------------------- the benchmark's own launch shapes
+
+def _psnr(y, ref):
+    return 10 * np.log10(float(ref.max() - ref.min()) ** 2 / max(float(np.mean((y - ref) ** 2)), 1e-30))
+
+
+def test_bench_frame_g24_fp32_launch_shapes_vs_oracle(dev):
+    """bench.py's timed configuration (BASELINE configs[1], G24): one 6000x4000 frame, UtNet(64) fp32, cs=264, 256 tiles per
+    conv-stack launch -- three-pass Winograd over a 256-tile chunk, split-K tail planning at that size, long plane offsets
+    (256 x 178 MB of activations) -- and the frame's last launch of 252 tiles (1276 = 4 x 256 + 252) in the 256-tile workspace.
+    The fused loop bench.py times == gather -> nd_utnet_forward -> stitch of the same five launches; sampled tiles of the first
+    and the last launch (first / last of the launch, some past index 128) against the oracle."""
+    from nind_denoise_amd import pipeline
+    from nind_denoise_amd.networks.UtNet import UtNet
+    from oracle import networks as onet
+    W, H, cs, ucs, ol, batch = 6000, 4000, 264, 200, 64, 256
+    sd = synth.make_utnet_state_dict(funit=64, seed=123)
+    net = UtNet()
+    net.load_state_dict(sd)
+    net = net.eval().to(dev)
+    img = torch.from_numpy(synth.make_frame(W, H, seed=24)).to(dev)
+    total = pipeline.tile_count(W, H, cs, ucs, ol)
+    assert total == 1276
+    fused = pipeline.denoise_frame(net, img, cs, ucs, ol, batch=batch)       # exactly bench.py's step
+    unfused = torch.zeros_like(img)
+    worst = 0.0
+    for first in range(0, total, batch):
+        count = min(batch, total - first)
+        x = pipeline.gather_tiles(img, cs, ucs, ol, first, count)
+        y = net(x)
+        assert torch.isfinite(y).all()
+        pipeline.stitch_tiles(unfused, y, cs, ucs, ol, first)
+        if first == 0 or first + count == total:
+            picks = sorted({0, 1, 129, count // 2 + 3, count - 2, count - 1})
+            with torch.no_grad():
+                ref = onet.utnet_forward(sd, x[picks].cpu())
+            for k, i in enumerate(picks):
+                worst = max(worst, assert_close(y[i:i + 1], ref[k:k + 1], f"G24 launch [{first},{first + count}) tile {i}"))
+        del x, y
+    print(f"G24 frame, 256 tiles per launch: worst max abs err over the sampled tiles {worst:.3e}")
+    err = (fused - unfused).abs().max().item()
+    scale = unfused.abs().max().item()
+    # same tiles, same kernels; the last launch runs 252 tiles in a 256-tile workspace on the fused side (split-K tail may differ)
+    assert err <= 1e-5 and scale > 0.01, (err, scale)
+
+
+def test_bench_launch_shape_g61_fp16_vs_oracle(dev):
+    """BASELINE configs[3] (G61): cs=520 / ucs=456 / ol=64, fp16 storage, several tiles per launch (the wide-row 2-stage conv
+    variants with a multi-image batch, tiles gathered from a frame with mirrored edges) against the fp32 oracle."""
+    from nind_denoise_amd import pipeline
+    from nind_denoise_amd.networks.UtNet import UtNet
+    from oracle import networks as onet
+    W, H, cs, ucs, ol = 2400, 1500, 520, 456, 64
+    sd = synth.make_utnet_state_dict(funit=64, seed=123)
+    net = UtNet()
+    net.load_state_dict(sd)
+    net = net.eval().to(dev)
+    img = torch.from_numpy(synth.make_frame(W, H, seed=61)).to(dev)
+    total = pipeline.tile_count(W, H, cs, ucs, ol)
+    n = 10
+    assert total >= n
+    x = pipeline.gather_tiles(img, cs, ucs, ol, total - n, n)        # the frame's last tiles: right / bottom mirrors
+    picks = [0, 4, n - 1]
+    with torch.no_grad():
+        ref = onet.utnet_forward(sd, x[picks].cpu()).numpy()
+    y32 = net(x)
+    for k, i in enumerate(picks):
+        assert_close(y32[i:i + 1], torch.from_numpy(ref[k:k + 1]), f"cs520 fp32 tile {i} of a {n}-tile launch")
+    for dtype, bar in (("f16", 85.0), ("bf16", 65.0)):
+        y = net.set_compute_dtype(dtype)(x).float().cpu().numpy()
+        assert np.isfinite(y).all()
+        worst = min(_psnr(y[i], ref[k]) for k, i in enumerate(picks))
+        print(f"G61 geometry, {n} tiles per launch, {dtype}: worst PSNR over sampled tiles {worst:.1f} dB")
+        assert worst >= bar, (dtype, worst)
+    # fused loop in fp16 == unfused loop, and both within the 16-bit bar of the fp32 canvas
+    net.set_compute_dtype("f16")
+    a = pipeline.denoise_frame(net, img, cs, ucs, ol, batch=n)
+    net.set_compute_dtype("f32")
+    c = pipeline.denoise_frame(net, img, cs, ucs, ol, batch=n)
+    rel = ((a - c).abs().max() / c.abs().max()).item()
+    assert rel < 0.002, rel
+
+
+# ---------------------------------------------------------------------------- multi-GPU entry with the HIP loop as compute
+
+def _sharded_worker(rank, world, port, geom, funit, outq):
+    import torch.distributed as tdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from nind_denoise_amd import dist as ndist
+    from nind_denoise_amd import pipeline
+    from nind_denoise_amd.networks.UtNet import UtNet
+    # one GPU per rank over RCCL when there are enough GPUs; else the ranks share GPU 0 and talk over gloo (RCCL refuses two
+    # ranks on one device): the same exchange logic and the same device loop, host-staged messages
+    shared = torch.cuda.device_count() < world
+    d = torch.device("cuda", 0 if shared else rank)
+    torch.cuda.set_device(d)
+    if shared:
+        tdist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        tdist.init_process_group("nccl", rank=rank, world_size=world, device_id=d)
+    try:
+        W, H, cs, ucs, ol, seed = geom
+        net = UtNet(funit=funit)
+        net.load_state_dict(synth.make_utnet_state_dict(funit=funit, seed=9))
+        net = net.eval().to(d)
+        net.split_k = False
+        geo = ndist.Geo(W, H, cs, ucs, ol)
+        frame = torch.from_numpy(synth.make_frame(W, H, seed=seed)).to(d) if rank == 0 else \
+            torch.full((3, H, W), float("nan"), device=d)
+        canvas = torch.full((3, H, W), 7.0, device=d)
+
+        def compute(fr, cv, lo, hi):
+            pipeline.denoise_frame(net, fr, cs, ucs, ol, batch=7, tile_range=(lo, hi), canvas=cv)
+
+        ndist.denoise_frame_sharded(compute, frame, canvas, geo)
+        torch.cuda.synchronize()
+        if rank == 0:
+            outq.put(canvas.cpu().numpy())
+    finally:
+        tdist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_sharded_frame_with_hip_compute(dev, world):
+    """dist.denoise_frame_sharded with the device loop as the per-rank compute: world size 1 over RCCL (backend "nccl"); world
+    size 2 over RCCL when two GPUs are visible, else both ranks on GPU 0 over gloo (host-staged messages).  Result == the
+    single-GPU canvas (seam rows re-associated: <= 1 ulp)."""
+    import socket
+    import torch.multiprocessing as mp
+    from nind_denoise_amd import pipeline
+    from nind_denoise_amd.networks.UtNet import UtNet
+    geom = (500, 430, 120, 88, 16, 3)
+    funit = 16
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, geom, funit, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    W, H, cs, ucs, ol, seed = geom
+    net = UtNet(funit=funit)
+    net.load_state_dict(synth.make_utnet_state_dict(funit=funit, seed=9))
+    net = net.eval().to(dev)
+    net.split_k = False
+    ref = pipeline.denoise_frame(net, torch.from_numpy(synth.make_frame(W, H, seed=seed)).to(dev), cs, ucs, ol, batch=7).cpu().numpy()
+    assert np.isfinite(got).all()
+    if world == 1:
+        assert np.array_equal(got, ref)
+    else:
+        assert np.abs(got - ref).max() <= 1e-6 and (got == ref).mean() > 0.7
