@@ -95,14 +95,18 @@ class OneImageDS(torch.utils.data.Dataset):
         if i < 0 or i >= self.size:
             raise IndexError(i)
         if self.whole_image:
-            # one item: the whole frame with a `pad`-wide symmetric mirror border (denoise_image.py:110-128; the
-            # reference's (W+2p, H+2p) allocation is only right for square frames -- H,W are used here)
+            # one item: the whole frame with its four SIDE bands mirrored (edge pixel repeated) and the four pad x pad
+            # corners left at zero, exactly as the reference builds it (denoise_image.py:110-128 mirrors the sides only);
+            # its (W+2p, H+2p) allocation is only right for square frames -- H, W are used in their places here
             p = self.pad
             if p:
                 def sym(n):   # edge pixel repeated, like np.flip of the adjacent band
                     i = torch.arange(-p, n + p, device=self.inimg.device)
                     return torch.where(i < 0, -1 - i, torch.where(i >= n, 2 * n - 1 - i, i))
                 ret = self.inimg[:, sym(self.height)][:, :, sym(self.width)].contiguous()
+                for ys in (slice(0, p), slice(self.height + p, None)):
+                    for xs in (slice(0, p), slice(self.width + p, None)):
+                        ret[:, ys, xs] = 0
             else:
                 ret = self.inimg
             usefuldim = (p, p, self.width + p, self.height + p)

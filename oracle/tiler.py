@@ -2,7 +2,7 @@
 
 Follows, line by line in meaning (not in text):
   * ``OneImageDS.__init__``      /root/reference/src/nind_denoise/denoise_image.py:88-107
-  * ``OneImageDS.__getitem__``   denoise_image.py:129-174   (tiled branch)
+  * ``OneImageDS.__getitem__``   denoise_image.py:129-174   (tiled branch), :110-128 (whole-image branch)
   * ``make_seamless_edges``      denoise_image.py:204-213
   * main-loop body (crop, +=)    denoise_image.py:249-267
 
@@ -78,6 +78,23 @@ def gather_tile(inimg, grid, i):
     if y1pad > 0:
         ret[:, cs - y1pad:, x0pad:cs - x1pad] = inimg[:, ye - y1pad:ye, xs:xe][:, ::-1, :]
     return ret
+
+
+def whole_image_item(inimg, pad):
+    """The single item of ``OneImageDS(whole_image=True, pad=pad)`` (denoise_image.py:110-128): the frame in the centre,
+    the four SIDE bands mirrored (edge pixel repeated), the four pad x pad corners left at ZERO -- the reference mirrors
+    the sides only.  Returns (item [3, H+2p, W+2p], usefuldim, usefulstart).  (The reference allocates (W+2p, H+2p), which
+    only works for square frames; H and W are used in their proper places here.)"""
+    p = int(pad or 0)
+    H, W = inimg.shape[1], inimg.shape[2]
+    ret = np.zeros((3, H + 2 * p, W + 2 * p), dtype=np.float32)
+    ret[:, p:H + p, p:W + p] = inimg
+    if p:
+        ret[:, p:-p, :p] = inimg[:, :, :p][:, :, ::-1]
+        ret[:, p:-p, W + p:] = inimg[:, :, W - p:][:, :, ::-1]
+        ret[:, :p, p:-p] = inimg[:, :p, :][:, ::-1, :]
+        ret[:, H + p:, p:-p] = inimg[:, H - p:, :][:, ::-1, :]
+    return ret, (p, p, W + p, H + p), (p, p)
 
 
 def make_seamless_edges(tcrop, x0, y0, grid):

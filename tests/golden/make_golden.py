@@ -13,8 +13,11 @@ module-level ``import`` statements succeed; none of them is executed by the code
 ``cv2.imread`` inside ``np_imgops.img_path_to_np_flt``, which is replaced by a function that returns the
 in-memory frame (the procedure SURVEY.md section 8c recorded as working, with nothing denied).
 
-The stitch loop of denoise_image.py (:204-213, :249-267) is ``__main__`` script code and cannot be imported;
-it is pinned through the identity-model round trip (tiler + stitch must reproduce the frame bit-exactly).
+The stitch loop of denoise_image.py (:204-213 ``make_seamless_edges``, :240-267 the loop) is ``__main__`` script code
+and cannot be imported: the two statements are located in the parsed source (``ast``) and executed here, in the
+build container, exactly as written (the loop runs over the reference's own ``OneImageDS`` through a
+``torch.utils.data.DataLoader``, with a cheap deterministic stand-in for the network); only the SHA-256 of the
+stitched canvas reaches the fixture -- no text of the reference is stored under tests/.
 
 Outputs (data only -- inputs / expected outputs / hashes):
   tiler_geoms.json          per geometry: grid, per-tile (x0,y0,ud,us) table hash + first/last rows,
@@ -23,7 +26,10 @@ Outputs (data only -- inputs / expected outputs / hashes):
   utnet_f64_cs264.npz       UtNet(64,'PReLU') output for synth weights seed 123 at cs=264 (+ digest of the weights)
   utnet_act_variants.npz    UtNet(funit=8, ELU / Hardswish) outputs at cs=104
   unet_256.npz              UNet() output for synth weights seed 0 on a 1x3x256x256 input
+  whole_image.json          OneImageDS(whole_image=True, pad=p) on square frames: sha256 of the item, usefuldim, usefulstart
+  stitch_main_loop.json     sha256 of the canvas the reference's own main loop builds (batch sizes 1 and 3) per geometry
 """
+import ast
 import hashlib
 import importlib
 import importlib.util
@@ -211,9 +217,88 @@ def unet_fixture(ref_tpn):
     print("unet done", missing, float(y.mean()))
 
 
+WHOLE = [
+    # (side, pad, seed): square frames only -- the reference allocates (3, W+2p, H+2p) (denoise_image.py:113), which is
+    # only consistent for W == H
+    (88, 8, 31),       # 88 + 16 = 104: a valid UtNet size, so the whole-image item can go through the network
+    (136, 8, 32),      # 152
+    (120, 0, 33),      # pad 0: the item is the frame itself
+    (97, 5, 34),       # odd everything
+]
+
+
+def whole_image_fixtures(ref_di):
+    import common.libs.np_imgops as ref_np_imgops
+    out = []
+    for side, pad, seed in WHOLE:
+        frame = synth.make_frame(side, side, seed=seed)
+        ref_np_imgops.img_path_to_np_flt = lambda fpath, _f=frame: _f
+        ds = ref_di.OneImageDS("in-memory", None, None, None, whole_image=True, pad=pad)
+        assert len(ds) == 1
+        t, ud, us = ds[0]
+        out.append(dict(side=side, pad=pad, seed=seed, shape=list(t.shape), item_sha=sha(t.numpy()), frame_sha=sha(frame),
+                        usefuldim=[int(v) for v in ud.tolist()], usefulstart=[int(v) for v in us.tolist()],
+                        corner_is_zero=bool(pad) and bool((t[:, :pad, :pad] == 0).all())))
+        print(f"whole image {side}x{side} pad {pad}: item {tuple(t.shape)}, corners zero: {out[-1]['corner_is_zero']}")
+    with open(os.path.join(HERE, "whole_image.json"), "w") as f:
+        json.dump(out, f)
+
+
+def stand_in_model(x):
+    """cheap deterministic stand-in for the network: [B,3,cs,cs] -> same (exact fp32 operations, one rounding per add)"""
+    return 0.5 * x + 0.25 * torch.roll(x, 1, dims=1) + 0.01
+
+
+def lift_main_loop():
+    """compile the reference's own ``make_seamless_edges`` and main ``for`` loop out of denoise_image.py's __main__ block"""
+    with open(os.path.join(REF, "denoise_image.py")) as f:
+        tree = ast.parse(f.read())
+    main_if = [n for n in tree.body if isinstance(n, ast.If) and "__main__" in ast.unparse(n.test)][0]
+    fdef = [n for n in main_if.body if isinstance(n, ast.FunctionDef) and n.name == "make_seamless_edges"][0]
+    loop = [n for n in main_if.body if isinstance(n, ast.For) and "DLoader" in ast.unparse(n.iter)][0]
+    mod_f = ast.Module(body=[fdef], type_ignores=[])
+    mod_l = ast.Module(body=[loop], type_ignores=[])
+    return compile(mod_f, "<reference make_seamless_edges>", "exec"), compile(mod_l, "<reference main loop>", "exec")
+
+
+def stitch_fixtures(ref_di):
+    import common.libs.np_imgops as ref_np_imgops
+    from torch.utils.data import DataLoader
+    code_f, code_l = lift_main_loop()
+    out = []
+    for (W, H, cs, ucs, ol, seed) in GEOMS[:8]:
+        frame = synth.make_frame(W, H, seed=seed)
+        ref_np_imgops.img_path_to_np_flt = lambda fpath, _f=frame: _f
+        shas = {}
+        for bs in (1, 3):
+            ds = ref_di.OneImageDS("in-memory", cs, ucs, ol)
+            ns = dict(ref_di.__dict__)          # the names the script body sees (torch, math, os, sys, ...)
+            ns.update(args=types.SimpleNamespace(overlap=ol, ucs=ucs, cs=cs, batch_size=bs, max_subpixels=None, whole_image=False,
+                                                 debug=False, input="in-memory"),
+                      fswidth=W, fsheight=H, ds=ds, device=torch.device("cpu"), model=stand_in_model,
+                      DLoader=DataLoader(dataset=ds, num_workers=0, drop_last=False, batch_size=bs, shuffle=False),
+                      newimg=torch.zeros(3, H, W, dtype=torch.float32), print=lambda *a, **k: None)
+            exec(code_f, ns)
+            exec(code_l, ns)
+            shas[str(bs)] = sha(ns["newimg"].numpy())
+        assert shas["1"] == shas["3"]
+        out.append(dict(W=W, H=H, cs=cs, ucs=ucs, ol=ol, seed=seed, canvas_sha=shas["1"], frame_sha=sha(frame)))
+        print(f"stitch {W}x{H} cs{cs} ucs{ucs} ol{ol}: canvas {shas['1'][:16]}")
+    with open(os.path.join(HERE, "stitch_main_loop.json"), "w") as f:
+        json.dump(out, f)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     ref_utnet, ref_tpn, ref_di = import_reference()
-    tiler_fixtures(ref_di)
-    utnet_fixtures(ref_utnet)
-    unet_fixture(ref_tpn)
+    only = set(sys.argv[1:])
+    if not only or "tiler" in only:
+        tiler_fixtures(ref_di)
+    if not only or "whole" in only:
+        whole_image_fixtures(ref_di)
+    if not only or "stitch" in only:
+        stitch_fixtures(ref_di)
+    if not only or "utnet" in only:
+        utnet_fixtures(ref_utnet)
+    if not only or "unet" in only:
+        unet_fixture(ref_tpn)

@@ -595,7 +595,8 @@ def test_utnet_non_square_and_whole_image(dev):
     assert len(ds) == 1
     t, ud, us = ds[0]
     assert tuple(t.shape) == (3, 104, 152) and tuple(ud.tolist()) == (8, 8, 144, 96) and tuple(us.tolist()) == (8, 8)
-    want = np.pad(frame, ((0, 0), (8, 8), (8, 8)), mode="symmetric")
+    from oracle import tiler as otiler
+    want = otiler.whole_image_item(frame, 8)[0]       # sides mirrored, corners zero (pinned by tests/golden/whole_image.json)
     assert np.array_equal(t.cpu().numpy(), want)
     y = net(t[None])[0][:, ud[1]:ud[3], ud[0]:ud[2]]
     with torch.no_grad():
@@ -1232,3 +1233,41 @@ def test_sharded_frame_with_hip_compute(dev, world):
         assert np.array_equal(got, ref)
     else:
         assert np.abs(got - ref).max() <= 1e-6 and (got == ref).mean() > 0.7
+
+
+# ---------------------------------------------------------------------------- fixtures executed by the reference itself
+
+def test_whole_image_item_vs_reference_fixture(dev, golden_dir):
+    # row a3: OneImageDS(whole_image=True, pad=p) as the reference builds it on square frames (sides mirrored, corners zero)
+    import hashlib
+    from nind_denoise_amd import denoise_image as di
+    with open(os.path.join(golden_dir, "whole_image.json")) as f:
+        cases = json.load(f)
+    for c in cases:
+        frame = synth.make_frame(c["side"], c["side"], seed=c["seed"])
+        ds = di.OneImageDS(frame, None, None, None, whole_image=True, pad=c["pad"], device=dev)
+        assert len(ds) == 1
+        t, ud, us = ds[0]
+        assert list(t.shape) == c["shape"] and ud.tolist() == c["usefuldim"] and us.tolist() == c["usefulstart"]
+        got = hashlib.sha256(np.ascontiguousarray(t.cpu().numpy()).tobytes()).hexdigest()
+        assert got == c["item_sha"], c
+
+
+def test_stitch_vs_reference_main_loop_fixture(dev, golden_dir):
+    # rows a8 / a9: the canvas the reference's own make_seamless_edges + main loop build (executed in the build container,
+    # tests/golden/make_golden.py) with a stand-in network of exact fp32 operations; device gather -> model -> device stitch
+    # must give the same bytes
+    import hashlib
+    from nind_denoise_amd import pipeline
+    with open(os.path.join(golden_dir, "stitch_main_loop.json")) as f:
+        cases = json.load(f)
+
+    def stand_in(x):
+        return 0.5 * x + 0.25 * torch.roll(x, 1, dims=1) + 0.01
+
+    for c in cases:
+        img = torch.from_numpy(synth.make_frame(c["W"], c["H"], seed=c["seed"])).to(dev)
+        for batch in (1, 7):
+            out = pipeline.denoise_frame(stand_in, img, c["cs"], c["ucs"], c["ol"], batch=batch)
+            got = hashlib.sha256(np.ascontiguousarray(out.cpu().numpy()).tobytes()).hexdigest()
+            assert got == c["canvas_sha"], (c["W"], c["H"], c["cs"], c["ucs"], c["ol"], batch)

@@ -217,3 +217,22 @@ def test_unet_module_state_dict_layout():
     lib = _lib.load()
     names = [lib.nd_unet_tensor_name(i).decode() for i in range(lib.nd_unet_num_tensors())]
     assert set(names) <= set(sd)
+
+
+def test_read_16bit_png_of_the_reference(golden_dir):
+    """The reference's own 16-bit test image (unittest_resources/NIND_bananapi_ISO50_20_30_104.png, a data file its
+    dataset_torch_3 tests hold; kept under tests/golden/) through the PNG reader and the reference's conversion rule
+    (np_imgops.py:12-29: RGB, CHW, uint16 / 65535; the alpha channel is dropped as cv2.IMREAD_COLOR does).  cv2 is absent, so the
+    decode is cross-checked against PIL, which reads the same file at 8 bits (the high byte of every sample)."""
+    from PIL import Image
+    from nind_denoise_amd.common.libs import imgcodec, np_imgops
+    path = os.path.join(golden_dir, "NIND_bananapi_ISO50_20_30_104.png")
+    raw = imgcodec.read_png(path)
+    assert raw.dtype == np.uint16 and raw.shape == (144, 144, 4)
+    assert raw.max() > 255 and (raw & 0xFF).std() > 10          # really 16 bits of signal, not 8 bits shifted
+    pil = np.asarray(Image.open(path))
+    assert pil.shape == raw.shape and np.array_equal((raw >> 8).astype(np.uint8), pil)
+    img = np_imgops.img_path_to_np_flt(path)
+    assert img.dtype == np.float32 and img.shape == (3, 144, 144)
+    assert np.array_equal(img, raw[:, :, :3].transpose(2, 0, 1).astype(np.float32) / 65535)
+    assert 0.0 <= img.min() and img.max() <= 1.0

@@ -114,3 +114,36 @@ def test_unet_matches_reference(golden_dir):
         y2 = onet.unet_forward(sd, torch.from_numpy(d["x2"]))
     assert np.abs(y.numpy() - d["y"]).max() <= 1e-5
     assert np.abs(y2.numpy() - d["y2"]).max() <= 1e-5
+
+
+def test_whole_image_item_vs_reference(golden_dir):
+    # OneImageDS(whole_image=True, pad=p) run by the reference itself on square frames (tests/golden/make_golden.py):
+    # sides mirrored, corners zero
+    with open(os.path.join(golden_dir, "whole_image.json")) as f:
+        cases = json.load(f)
+    assert any(c["corner_is_zero"] for c in cases)
+    for c in cases:
+        frame = synth.make_frame(c["side"], c["side"], seed=c["seed"])
+        assert sha(frame) == c["frame_sha"]
+        item, ud, us = otiler.whole_image_item(frame, c["pad"])
+        assert list(item.shape) == c["shape"] and list(ud) == c["usefuldim"] and list(us) == c["usefulstart"]
+        assert sha(item) == c["item_sha"], c
+
+
+def _stand_in(x):
+    # the stand-in network of make_golden.py (exact fp32 operations, one rounding per add)
+    return np.float32(0.5) * x + np.float32(0.25) * np.roll(x, 1, axis=1) + np.float32(0.01)
+
+
+@pytest.mark.parametrize("batch", [1, 4])
+def test_stitch_vs_reference_main_loop(golden_dir, batch):
+    # canvas hashes produced by the reference's own make_seamless_edges + main loop (denoise_image.py:204-213, 240-267),
+    # executed in the build container over the reference's OneImageDS with the stand-in network
+    with open(os.path.join(golden_dir, "stitch_main_loop.json")) as f:
+        cases = json.load(f)
+    assert len(cases) == 8
+    for c in cases:
+        frame = synth.make_frame(c["W"], c["H"], seed=c["seed"])
+        assert sha(frame) == c["frame_sha"]
+        out = otiler.denoise_frame(frame, c["cs"], c["ucs"], c["ol"], _stand_in, batch=batch)
+        assert sha(out) == c["canvas_sha"], (c["W"], c["H"], c["cs"], c["ucs"], c["ol"])
