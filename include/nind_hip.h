@@ -57,8 +57,10 @@ typedef enum nd_flags {
     ND_FLAG_NO_SPLITK = 1,    /* keep every output tile whole: no split-K tail, so a tile's bits do not depend on which other
                                  tiles share its launch (the default splits the K loop of a launch's last, partial round of
                                  workgroups over the idle CUs: deterministic, but fp32 sums re-associate by <= 1e-5)        */
-    ND_FLAG_DIRECT_CONV = 2   /* direct convolution on every 3x3 layer (default on the fp32 path: Winograd F(4x4,3x3) from
+    ND_FLAG_DIRECT_CONV = 2,  /* direct convolution on every 3x3 layer (default on the fp32 path: Winograd F(4x4,3x3) from
                                  128 channels up, 1-D F(4,3) inside the implicit-GEMM kernel below; ~1e-5 re-association)   */
+    ND_FLAG_W1D_REGS = 4      /* A/B switch: the 1-D F(4,3) layers through the kernel that transforms in registers (conv_w1d)
+                                 instead of the one that shares the transform through LDS (conv_w2d, the default)            */
 } nd_flags;
 
 int nd_version(void);
@@ -235,7 +237,8 @@ int nd_ssim_loss_grad(const float *x, const float *y, int n, int c, int h, int w
 /* ---- Winograd forms of a 3x3 layer, fp32 inference (same math as nd_layer_forward on a CONV3 / CONVT3 layer, re-associated).
  * tile = 2 | 4: three-pass F(tile x tile, 3 x 3) (input transform, one launch of (tile+2)^2 GEMMs, output transform;
  *               Cin % 16 == 0; agrees with the direct kernel to ~1e-6 / ~1e-5 relative);
- * tile = 1 | 3: 1-D F(2,3) | F(4,3) along x inside the implicit-GEMM kernel (~1e-6 / ~5e-6). */
+ * tile = 1 | 3: 1-D F(2,3) | F(4,3) along x inside the implicit-GEMM kernel, transform in registers (~1e-6 / ~5e-6);
+ * tile = 5    : the same F(4,3) form with the input transform shared by the workgroup through LDS (conv_w2d). */
 size_t nd_winograd_packed_bytes(int tile, int cin, int cout);
 int nd_winograd_pack(int tile, int kind, int cin, int cout, const float *w, const float *bias, void *packed,
                      size_t packed_bytes);

@@ -260,7 +260,7 @@ int nd_launch_conv(const ConvDesc &d, hipStream_t stream) {
     if (V.taps != taps || V.up != up || V.dt != dt) ND_FAIL(ND_EINVAL, "conv: variant %s does not match layer kind %d / dtype %d", V.name, d.kind, dt);
     if (KB % V.kbc) ND_FAIL(ND_EINVAL, "conv: Cin/8=%d not a multiple of the variant's K chunk %d", KB, V.kbc);
 
-    ConvParams p;
+    ConvParams p = {};
     p.in = (const f32x4 *)d.in.base + (long)d.in_plane0 * d.in.np();
     p.wpk = d.wpk;
     p.bias = d.bias;

@@ -90,6 +90,12 @@ size_t nd_w1d_packed_floats(int T, int cin, int cout);
 int nd_w1d_pack(int T, int kind, int cin, int cout, const float *w, const float *bias, float *packed);
 bool nd_w1d_fits(int T, const QpBuf &in);
 int nd_launch_conv_w1d(int T, const ConvDesc &d, hipStream_t stream);
+// the same F(4,3) layer with the input transform shared by the workgroup through LDS (conv_w2d.hip; same packed weights as T = 4)
+bool nd_w2d_ok(const QpBuf &in);
+int nd_launch_conv_w2d(const ConvDesc &d, hipStream_t stream);
+// slack (16-byte elements) behind the last plane of an activation buffer: an N tile of the conv kernels may read a 3x3 halo past
+// the last pixel, a strip of conv_w2d up to 9 rows + 5 pixels
+static inline size_t nd_buf_slack(int Wb) { return (size_t)10 * Wb + 8 + 2048; }
 const char *nd_conv_variant_label(int v);
 
 // packed size helpers (host)

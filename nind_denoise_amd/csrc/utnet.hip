@@ -135,7 +135,7 @@ static int forward_common(int funit, int act, int dtype, const void *packed, int
 }
 
 static int check_flags(int flags) {
-    if (flags & ~(ND_FLAG_NO_SPLITK | ND_FLAG_DIRECT_CONV)) ND_FAIL(ND_EINVAL, "unknown flag bits 0x%x", flags);
+    if (flags & ~(ND_FLAG_NO_SPLITK | ND_FLAG_DIRECT_CONV | ND_FLAG_W1D_REGS)) ND_FAIL(ND_EINVAL, "unknown flag bits 0x%x", flags);
     return ND_OK;
 }
 extern "C" int nd_utnet_forward_hw(int funit, int act, int dtype, int flags, const void *packed, const float *x, float *y,
@@ -309,7 +309,7 @@ LayerPlan layer_plan(int kind, int B, int cin, int cout, int h, int w, char *bas
     p.in.pad = ipad;
     p.in.pstride = (long)B * p.in.Hb * p.in.Wb;
     p.in.base = (float *)base;
-    size_t off = ((size_t)p.in.planes * p.in.pstride + 2 * p.in.Wb + 2 + 2048) * 16;
+    size_t off = ((size_t)p.in.planes * p.in.pstride + nd_buf_slack(p.in.Wb)) * 16;
     off = (off + 255) & ~(size_t)255;
     int oh, ow;
     switch (kind) {
@@ -377,9 +377,10 @@ extern "C" int nd_layer_forward(int kind, int act, float slope, int dtype, const
 
 // Winograd form of a 3x3 layer (tile = 2 | 4): same interface as nd_layer_forward with a blob from nd_winograd_pack
 // (tile = 1 | 3: the 1-D F(2,3) | F(4,3) form fused into the implicit-GEMM kernel, conv_w1d.hip)
-static bool wino_tile_ok(int tile) { return tile >= 1 && tile <= 4; }
+static bool wino_tile_ok(int tile) { return tile >= 1 && tile <= 5; }   // 5: the F(4,3) form of tile 3 through conv_w2d
 extern "C" size_t nd_winograd_packed_bytes(int tile, int cin, int cout) {
     if (!wino_tile_ok(tile) || cin <= 0 || cout <= 0) return 0;
+    if (tile == 5) tile = 3;
     return ((tile & 1) ? nd_w1d_packed_floats(tile + 1, cin, cout) : nd_wino_packed_floats(tile, cin, cout)) * sizeof(float);
 }
 extern "C" int nd_winograd_pack(int tile, int kind, int cin, int cout, const float *w, const float *bias, void *packed,
@@ -387,6 +388,7 @@ extern "C" int nd_winograd_pack(int tile, int kind, int cin, int cout, const flo
     const size_t need = nd_winograd_packed_bytes(tile, cin, cout);
     if (!need) ND_FAIL(ND_EINVAL, "nd_winograd_pack: bad shape");
     if (!packed || packed_bytes < need) ND_FAIL(ND_ENOMEM, "nd_winograd_pack: %zu B given, %zu B needed", packed_bytes, need);
+    if (tile == 5) tile = 3;
     if (tile & 1) return nd_w1d_pack(tile + 1, kind, cin, cout, w, bias, (float *)packed);
     return nd_wino_pack(tile, kind, cin, cout, w, bias, (float *)packed);
 }
@@ -425,7 +427,10 @@ extern "C" int nd_layer_forward_winograd(int tile, int kind, int act, float slop
     d.part = pl.split;
     d.part_bytes = kSplitScratchBytes;
     d.nosplit = (flags & ND_FLAG_NO_SPLITK) != 0;
-    if (tile & 1) {
+    if (tile == 5) {
+        d.bias = d.wpk + (size_t)nd_mtiles(ND_CONV3, cout) * nd_kblocks(cin) * 3 * 6 * 256;
+        ND_TRY(nd_launch_conv_w2d(d, s));
+    } else if (tile & 1) {
         d.bias = d.wpk + (size_t)nd_mtiles(ND_CONV3, cout) * nd_kblocks(cin) * 3 * (tile + 3) * 256;
         ND_TRY(nd_launch_conv_w1d(tile + 1, d, s));
     } else {
@@ -548,7 +553,7 @@ extern "C" int nd_winograd_bench(int tile, int kind, int batch, int cin, int cou
                                  size_t ws_bytes, void *stream, float *mean_ms) {
     const size_t need = nd_layer_winograd_workspace_bytes(tile, kind, batch, cin, cout, h, w);
     if (!need) ND_FAIL(ND_EINVAL, "nd_winograd_bench: bad shape / kind / tile");
-    const size_t wfloats = (tile & 1) ? nd_w1d_packed_floats(tile + 1, cin, cout) : nd_wino_packed_floats(tile, cin, cout);
+    const size_t wfloats = (tile & 1) ? nd_w1d_packed_floats(tile == 5 ? 4 : tile + 1, cin, cout) : nd_wino_packed_floats(tile, cin, cout);
     const size_t total = ((need + 255) & ~(size_t)255) + wfloats * 4;
     if (!ws || ws_bytes < total) ND_FAIL(ND_ENOMEM, "nd_winograd_bench: workspace %zu B given, %zu B needed", ws_bytes, total);
     hipStream_t s = (hipStream_t)stream;
@@ -573,8 +578,10 @@ extern "C" int nd_winograd_bench(int tile, int kind, int batch, int cin, int cou
     d.part_bytes = kSplitScratchBytes;
     void *scratch = (char *)ws + pl.bytes;
     const size_t scratch_bytes = need - pl.bytes;
-    if (tile & 1) d.bias = d.wpk + (size_t)nd_mtiles(ND_CONV3, cout) * nd_kblocks(cin) * 3 * (tile + 3) * 256;
-    auto run = [&]() { return (tile & 1) ? nd_launch_conv_w1d(tile + 1, d, s) : nd_launch_conv_wino(tile, d, scratch, scratch_bytes, s); };
+    if (tile & 1) d.bias = d.wpk + (size_t)nd_mtiles(ND_CONV3, cout) * nd_kblocks(cin) * 3 * ((tile == 5 ? 3 : tile) + 3) * 256;
+    auto run = [&]() {
+        return tile == 5 ? nd_launch_conv_w2d(d, s) : ((tile & 1) ? nd_launch_conv_w1d(tile + 1, d, s) : nd_launch_conv_wino(tile, d, scratch, scratch_bytes, s));
+    };
     ND_TRY(run());
     hipEvent_t e0, e1;
     ND_HIP(hipEventCreate(&e0));

@@ -196,8 +196,7 @@ Plan make_plan(int f, int ch_, int cw_, int cap, int nimg, char *base, int dt) {
         q.pad = pad;
         q.pstride = (long)cap * q.Hb * q.Wb;
         q.base = (float *)(base + off);
-        // slack: an N tile may read (tile + 3x3 halo) pixels past the last plane
-        const size_t slack = (size_t)(2 * q.Wb + 2 + 2048);
+        const size_t slack = nd_buf_slack(q.Wb);   // reads past the last plane (halo of the last tile / strip)
         off += ((size_t)q.planes * q.pstride + slack) * 16;
         off = (off + 255) & ~(size_t)255;
     };
@@ -252,6 +251,7 @@ inline Form step_form(const Step &st, int f, int dt, int flags, const Plan &pl, 
     if (train) return (train_w1 && train_w1[st.layer]) ? FORM_W1D4 : FORM_DIRECT;
     if (flags & ND_FLAG_DIRECT_CONV) return FORM_DIRECT;
     if (bl.w1off[st.layer]) {
+        if (!(flags & ND_FLAG_W1D_REGS) && nd_w2d_ok(pl.buf[st.src])) return FORM_W1D4;   // conv_w2d: any row width
         if (nd_w1d_fits(kW1dTile, pl.buf[st.src])) return FORM_W1D4;
         if (nd_w1d_fits(2, pl.buf[st.src])) return FORM_W1D2;
         return FORM_DIRECT;
@@ -305,7 +305,10 @@ int run_stack(int f, int act, int dt, const float *blob, const Plan &pl, hipStre
             const int T = form == FORM_W1D4 ? kW1dTile : 2;
             if (!pre) d.wpk = blob + (T == kW1dTile ? bl.w1off[st.layer] : bl.w1off2[st.layer]);
             d.bias = d.wpk + (size_t)nd_mtiles(ND_CONV3, d.cout) * nd_kblocks(d.cin) * 3 * (T + 2) * 256;
-            ND_TRY(nd_launch_conv_w1d(T, d, s));
+            if (T == 4 && !pre && !(flags & ND_FLAG_W1D_REGS))
+                ND_TRY(nd_launch_conv_w2d(d, s));     // inference: transform shared through LDS (conv_w2d.hip)
+            else
+                ND_TRY(nd_launch_conv_w1d(T, d, s));
             continue;
         }
         if (form == FORM_WINO3P) {

@@ -32,8 +32,10 @@ class UtNet(nn.Module):
     # per-call arithmetic flags (nd_flags of include/nind_hip.h), overridable per instance:
     #   split_k = False  -> every output tile whole: a tile's bits do not depend on the batch grouping
     #   winograd = False -> direct convolution on every 3x3 layer
+    #   w1d_regs = True  -> A/B switch: the fused 1-D Winograd layers through conv_w1d (transform in registers) instead of conv_w2d
     split_k = True
     winograd = True
+    w1d_regs = False
 
     def __init__(self, funit=64, activation='PReLU'):
         super().__init__()
@@ -85,7 +87,8 @@ class UtNet(nn.Module):
 
     @property
     def flags(self):
-        return (0 if self.split_k else _lib.FLAG_NO_SPLITK) | (0 if self.winograd else _lib.FLAG_DIRECT_CONV)
+        return ((0 if self.split_k else _lib.FLAG_NO_SPLITK) | (0 if self.winograd else _lib.FLAG_DIRECT_CONV) |
+                (_lib.FLAG_W1D_REGS if self.w1d_regs else 0))
 
     # ------------------------------------------------------------------ weights
     def _weights_key(self, device):
