@@ -22,6 +22,8 @@
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 constexpr int kR = 8;                         // output rows per strip
 constexpr int kS = 16;                        // strips per workgroup tile
 constexpr int kRI = kR + 2;                   // input rows per strip
@@ -35,9 +37,8 @@ constexpr int kStage = kWBytes + kVBytes;
 constexpr int kStages = 2;
 constexpr int kScratch = 2048;                // per wave: epilogue transpose (8 rows x 16 pixels of one channel quad)
 constexpr int kLds = kStages * kStage + 8 * kScratch;   // 151,552 B
-constexpr int kXfLanes = 40;                  // lanes of every wave that own one lane-transform per K step (8 x 40 = 320)
-constexpr int kSlots = 4 * 32 * 4;            // pixel slots of a tile in the split-K scratch: (wave column, lane, pixel)
 constexpr int kXfAt = 12;                     // the transform of the next step's pixels sits after this many (ky, position) groups
+constexpr int kSlots = 4 * 32 * 4;            // pixel slots of a tile in the split-K scratch: (wave column, lane, pixel)
 
 // slot of strip s in row r of a V plane: XOR-swizzled so that the 16 lanes of a ds_read_b128 group (4 strips x 4 rows of one wave)
 // hit 16 different bank quads without padding the rows
@@ -127,72 +128,98 @@ __global__ __launch_bounds__(512) void conv_w2d(ConvParams p) {
         return r;
     };
 
-    // ---- fill cursor: the (tile, K chunk) stream one step ahead of the MFMA loop.  Every wave takes an equal share of both jobs
-    // (so that no wave reaches the step's barrier late): weights by LDS-DMA, 36 pieces of 1 KiB per step -> waves 0..3 five
-    // pieces, waves 4..7 four; activations: lanes 0..39 of every wave load one (strip, input row, channel-quad half) pixel
-    // group into registers and transform it in the middle of the wave's own MFMA stream.
+    // ---- fill cursor: the (tile, K chunk) stream one step ahead of the MFMA loop.
+    // Who does the memory work matters: of the two waves of a SIMD the OLDER one (waves 0..3) wins the matrix pipe, finishes its
+    // 72 MFMAs first and then waits ~4,800 cycles at the step's barrier, while the younger one (waves 4..7) is the step's critical
+    // path (in-kernel stamps).  So waves 4..7 only multiply and store; waves 0..3 load and transform the
+    // pixels (pass A: 4 x 64 = 256 of the 320 lane-transforms, pass B: the other 64 on wave 0) and waves 1..3 issue the 36
+    // weight pieces (12 each) by LDS-DMA -- all of it while their SIMD partners already run MFMAs.
     int f_id = vb, f_c = 0, f_end = 0, f_stage = 0, issued = 0;
     const float *f_w;
-    const int xt = wave * kXfLanes + lane;                     // lane-transform id (lanes 0..39)
-    const bool xf_lane = lane < kXfLanes;
-    const int x_h = xt / (kS * kRI), x_i = (xt / kS) % kRI, x_s = xt % kS;
-    const int vwOff = kWBytes + x_h * kVPlane + vslot(x_i, x_s) * 16;   // where this lane writes v[position 0]
-    unsigned x_off = 0;   // float4 index of this lane's 6 input pixels inside the two-plane window of a K block
-    int x_keep = 6;       // inputs [0, keep) feed in-row outputs (6 unless the group hangs over the row end)
+    const bool xfA = wave < 4, xfB = wave == 0;
+    int vwOff[2];
+    int x_h[2], x_i[2], x_s[2];
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        const int xt = ps == 0 ? (wave & 3) * 64 + lane : 256 + lane;      // lane-transform id
+        x_h[ps] = xt / (kS * kRI);
+        x_i[ps] = (xt / kS) % kRI;
+        x_s[ps] = xt % kS;
+        vwOff[ps] = kWBytes + x_h[ps] * kVPlane + vslot(x_i[ps], x_s[ps]) * 16;   // where this lane writes v[position 0]
+    }
+    unsigned x_off[2] = {0, 0};   // float4 index of the lane's 6 input pixels inside the two-plane window of a K block
+    int x_keep[2] = {6, 6};       // inputs [0, keep) feed in-row outputs (6 unless the group hangs over the row end)
     auto set_fill_tile = [&](int w) {
         const Item it = decode(w);
         f_c = it.c0;
         f_end = it.c1;
         const int nb = it.tile / p.n_tiles_m, mb = it.tile - nb * p.n_tiles_m;
-        // this wave's weight pieces: 4 consecutive KiB of the stage image, + one of the last four for waves 0..3
         f_w = p.wpk + (size_t)mb * kMTB * p.KB * kTaps * 256 + lane * 4;
-        if (xf_lane) {
-            const Strip st = strip_of(nb, x_s);
-            x_off = (unsigned)x_h * (unsigned)p.in_plane + (unsigned)st.img * (unsigned)p.P + (unsigned)(st.y0 + x_i) * p.Wb + st.x0;
-            const int left = p.wpx - st.x0;
-            x_keep = left + 2 < 6 ? left + 2 : 6;
-        }
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps)
+            if (ps == 0 ? xfA : xfB) {
+                const Strip st = strip_of(nb, x_s[ps]);
+                x_off[ps] = (unsigned)x_h[ps] * (unsigned)p.in_plane + (unsigned)st.img * (unsigned)p.P + (unsigned)(st.y0 + x_i[ps]) * p.Wb + st.x0;
+                const int left = p.wpx - st.x0;
+                x_keep[ps] = left + 2 < 6 ? left + 2 : 6;
+            }
     };
     set_fill_tile(f_id);
-    f32x4 dn[6];
+    f32x4 dn[2][6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) dn[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // issue the loads of the next step (weights by DMA into its stage, raw pixels into registers)
-    auto fill_issue = [&]() {
-        if (issued >= nsteps) return;
-        char *sb = smem + f_stage * kStage;
-        if (!(DBG & 4)) {
-            // stage image of the weights = [M tile mt][plane]: piece q lives at mt = q / 18, plane q % 18 of K block f_c
-            auto piece = [&](int q) {
-                const int mt = q / kTaps, pl = q - mt * kTaps;
-                glds16(f_w + ((size_t)mt * p.KB + (size_t)f_c) * kTaps * 256 + pl * 256, sb + q * 1024);
-            };
+    for (int ps = 0; ps < 2; ++ps)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) piece(4 * wave + k);
-            if (wave < 4) piece(32 + wave);
+        for (int k = 0; k < 6; ++k) dn[ps][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // The next step's loads, issued at the top of the step: the raw pixels into registers (fill_loads), then the weight DMA
+    // (fill_dma) -- in this order: hipcc puts an s_waitcnt vmcnt(0) in front of a register load that follows an LDS-DMA (measured:
+    // ~2,000 cycles per step with the other order).  fill_xform, in the middle of the wave's own MFMA stream: transform + publish.
+    // (Also measured, and not better: the loads dealt out one per MFMA group; transform + DMA after the wave's MFMAs at raised
+    // priority -- DESIGN.md section 4.)
+    auto fill_loads = [&]() {
+        if (issued >= nsteps || (DBG & 8)) return;
+        if (xfA) {
+            const f32x4 *src = p.in + (size_t)(2 * f_c) * p.in_plane + x_off[0];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) dn[0][k] = src[k];
         }
-        if (xf_lane && !(DBG & 8)) {
-            const f32x4 *src = p.in + (size_t)(2 * f_c) * p.in_plane + x_off;
+        if (xfB) {
+            const f32x4 *src = p.in + (size_t)(2 * f_c) * p.in_plane + x_off[1];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) dn[k] = src[k];
+            for (int k = 0; k < 6; ++k) dn[1][k] = src[k];
         }
     };
-    // transform the pixels loaded by the last fill_issue and publish them in that step's V image; advance the cursor
-    auto fill_finish = [&]() {
-        if (issued >= nsteps) return;
-        if (xf_lane && !(DBG & 16)) {
-            if (__builtin_amdgcn_ballot_w64(x_keep < 6)) {   // some lane's group hangs over its row end (1 group in ~66)
-                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    auto fill_xform = [&]() {
+        if (issued >= nsteps || (DBG & 16)) return;
 #pragma unroll
-                for (int k = 3; k < 6; ++k)
-                    if (k >= x_keep) dn[k] = zero;
+        for (int ps = 0; ps < 2; ++ps)
+            if (ps == 0 ? xfA : xfB) {
+                if (__builtin_amdgcn_ballot_w64(x_keep[ps] < 6)) {   // some lane's group hangs over its row end (1 group in ~66)
+                    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 3; k < 6; ++k)
+                        if (k >= x_keep[ps]) dn[ps][k] = zero;
+                }
+                f32x4 v[6];
+                w4_in(dn[ps], v);
+                char *dst = smem + f_stage * kStage + vwOff[ps];
+#pragma unroll
+                for (int x = 0; x < 6; ++x) *(f32x4 *)(dst + x * kVPos) = v[x];
             }
-            f32x4 v[6];
-            w4_in(dn, v);
-            char *dst = smem + f_stage * kStage + vwOff;
+    };
+    auto fill_dma = [&]() {
+        if (issued >= nsteps || (DBG & 4)) return;
+        if (wave >= 1 && wave < 4) {
+            // stage image of the weights = [M tile mt][plane]: piece q lives at mt = q / 18, plane q % 18 of K block f_c
 #pragma unroll
-            for (int x = 0; x < 6; ++x) *(f32x4 *)(dst + x * kVPos) = v[x];
+            for (int k = 0; k < 12; ++k) {
+                const int q = (wave - 1) * 12 + k;
+                const int mt = q / kTaps, pl = q - mt * kTaps;
+                glds16(f_w + ((size_t)mt * p.KB + (size_t)f_c) * kTaps * 256 + pl * 256, smem + f_stage * kStage + q * 1024);
+            }
         }
+    };
+    auto fill_advance = [&]() {
+        if (issued >= nsteps) return;
         ++issued;
         f_stage ^= 1;
         if (++f_c == f_end) {
@@ -236,35 +263,62 @@ __global__ __launch_bounds__(512) void conv_w2d(ConvParams p) {
 
     // Epilogue of a finished tile.  A lane's 4 pixels x 4 channels go through a 2 KiB per-wave LDS scratch, one channel quad
     // at a time ([8 rows][16 pixels] of 16 bytes), so that the stores leave as 256-byte row segments (16 lanes x 16 B contiguous,
-    // 4 segments per wave instruction) instead of 64 separate 16-byte pieces at a 64-byte stride.
+    // 4 segments per wave instruction) instead of 64 separate 16-byte pieces at a 64-byte stride.  Every VALU instruction here
+    // is matrix-pipe time (see the header), so: packed fp32 arithmetic on adjacent accumulator registers, the bias in registers
+    // (loaded when the tile starts), PReLU as max(t, slope * t) when 0 <= slope <= 1, store offsets computed once per tile.
     char *const scratch = smem + kStages * kStage + wave * kScratch;
     const int e_row = lane >> 4, e_px = lane & 15;                  // reader side: rows e_row and e_row + 4, pixel e_px of the wave's 16
+    f32x4 biasq[4];                                                 // bias of channels 8g + 4h .. + 3 of this wave's M tile
+    auto load_bias = [&](int id) {
+        const int mb = id % p.n_tiles_m;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) biasq[g] = *(const f32x4 *)(p.bias + (mb * kMTB + wm) * 32 + 8 * g + 4 * h);
+    };
+    load_bias(decode(vb).tile);
     auto epilogue = [&](int id, auto fast) {
         const int nb = id / p.n_tiles_m, mb = id - nb * p.n_tiles_m;
         const Strip st = strip_of(nb, 4 * wn + (e_px >> 2));        // the strip this lane STORES for
         const int ex = st.x0 + (e_px & 3);
-        const long pixA = (long)st.img * p.Po + (long)(st.y0 + e_row + p.opad) * p.Wo + ex + p.opad;
+        const unsigned offA = (unsigned)((st.img * p.Po + (st.y0 + e_row + p.opad) * p.Wo + ex + p.opad) * 16);   // bytes inside a plane (< 2^32)
+        const unsigned offB = offA + (unsigned)(4 * p.Wo * 16);
         const bool okx = st.ok && ex < p.wpx;
         const bool okA = okx && st.y0 + e_row < p.Hv, okB = okx && st.y0 + e_row + 4 < p.Hv;
+        const int q0 = (mb * kMTB + wm) * 8;                        // first channel quad of this wave's M tile
+        const f32x2 slope2 = {slope, slope};
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int m8 = ((mb * kMTB + wm) * 32) + 8 * g;
-            const f32x8 b8 = sload8(p.bias + m8);
             f32x4 yy[4];
-            combine(g, yy);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int pr = 0; pr < 2; ++pr) {
+                f32x2 m[6];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float t = yy[i][e] + (h ? b8[4 + e] : b8[e]);
-                    if constexpr (decltype(fast)::value)
-                        yy[i][e] = fmaxf(t, t * slope);
-                    else
-                        yy[i][e] = apply_act(t, p.act, slope);
+                for (int x = 0; x < 6; ++x) {
+                    m[x] = f32x2{acc[x][4 * g + 2 * pr], acc[x][4 * g + 2 * pr + 1]};
+                    acc[x][4 * g + 2 * pr] = 0.f;
+                    acc[x][4 * g + 2 * pr + 1] = 0.f;
                 }
+                const f32x2 bq = {biasq[g][2 * pr], biasq[g][2 * pr + 1]};
+                const f32x2 a = m[1] + m[2] + bq, b = m[1] - m[2] + bq, c = m[3] + m[4], e = m[3] - m[4];   // A^T m, bias folded in once
+                f32x2 y[4];
+                y[0] = m[0] + a + c;
+                y[1] = b + 2.f * e;
+                y[2] = a + 4.f * c;
+                y[3] = b + 8.f * e + m[5];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if constexpr (decltype(fast)::value) {
+                        const f32x2 t = y[i] * slope2;
+                        y[i] = f32x2{fmaxf(y[i][0], t[0]), fmaxf(y[i][1], t[1])};
+                    } else {
+                        y[i] = f32x2{apply_act(y[i][0], p.act, slope), apply_act(y[i][1], p.act, slope)};
+                    }
+                    yy[i][2 * pr] = y[i][0];
+                    yy[i][2 * pr + 1] = y[i][1];
+                }
+            }
             if (DBG & 256) {   // diagnostic: the untransposed stores (each lane its own 4 pixels, 16-byte pieces at a 64-byte stride)
                 const Strip so = strip_of(nb, sl);
-                const int yo = so.y0 + rr, m4 = m8 + 4 * h, left = p.wpx - so.x0;
+                const int yo = so.y0 + rr, m4 = (q0 + 2 * g + h) * 4, left = p.wpx - so.x0;
                 if (so.ok && yo < p.Hv && m4 < p.M) {
                     f32x4 *dst = p.out + (long)(p.out_plane0 + (m4 >> 2)) * p.out_plane + (long)so.img * p.Po + (long)(yo + p.opad) * p.Wo + so.x0 + p.opad;
 #pragma unroll
@@ -291,11 +345,11 @@ __global__ __launch_bounds__(512) void conv_w2d(ConvParams p) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const int m4 = m8 + 4 * hq;
-                if (m4 < p.M && !(DBG & 1)) {
-                    f32x4 *dst = p.out + (long)(p.out_plane0 + (m4 >> 2)) * p.out_plane + pixA;
-                    if (okA) dst[0] = va;
-                    if (okB) dst[4 * (long)p.Wo] = vb2;
+                const int quad = q0 + 2 * g + hq;
+                if (quad * 4 < p.M && !(DBG & 1)) {
+                    char *pb = (char *)(p.out + (size_t)(p.out_plane0 + quad) * p.out_plane);   // wave-uniform plane base
+                    if (okA) *(f32x4 *)(pb + offA) = va;
+                    if (okB) *(f32x4 *)(pb + offB) = vb2;
                 }
             }
         }
@@ -314,8 +368,10 @@ __global__ __launch_bounds__(512) void conv_w2d(ConvParams p) {
     };
 
     // ---- prologue: step 0's weights and V image
-    fill_issue();
-    fill_finish();
+    fill_loads();
+    fill_xform();
+    fill_dma();
+    fill_advance();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
@@ -325,7 +381,8 @@ __global__ __launch_bounds__(512) void conv_w2d(ConvParams p) {
     unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;   // DBG & 128: cycles per phase, summed over the steps
     for (int s = 0; s < nsteps; ++s) {
         if (DBG & 128) t0 = stamp();
-        fill_issue();                       // next step's loads fly under this step's MFMAs
+        fill_loads();                       // next step's pixels and weights fly under this step's MFMAs
+        fill_dma();
         __builtin_amdgcn_sched_barrier(0);
         if (DBG & 128) { t1 = stamp(); tph[0] += t1 - t0; t0 = t1; }
         const char *wa = smem + c_stage * kStage + aOff;
@@ -354,7 +411,8 @@ __global__ __launch_bounds__(512) void conv_w2d(ConvParams p) {
                 // own MFMA stream (the SIMD partner's MFMAs fill the matrix pipe meanwhile), and publish them in the OTHER stage
                 __builtin_amdgcn_sched_barrier(0);
                 if (DBG & 128) { t1 = stamp(); tph[1] += t1 - t0; t0 = t1; }
-                fill_finish();
+                fill_xform();
+                fill_advance();
                 if (DBG & 128) { t1 = stamp(); tph[3] += t1 - t0; t0 = t1; }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -376,7 +434,10 @@ __global__ __launch_bounds__(512) void conv_w2d(ConvParams p) {
             else
                 epilogue(c_it.tile, std::false_type{});
             c_id += nwg;
-            if (c_id < nitems) c_it = decode(c_id);
+            if (c_id < nitems) {
+                c_it = decode(c_id);
+                if (p.n_tiles_m > 1) load_bias(c_it.tile);   // (one M tile: the registers already hold it)
+            }
             c_c = c_it.c0;
         }
         if (DBG & 128) { t1 = stamp(); tph[4] += t1 - t0; t0 = t1; }
@@ -531,7 +592,7 @@ int nd_launch_conv_w2d(const ConvDesc &d, hipStream_t stream) {
         if (printed++ < 2) {
             std::vector<unsigned long long> h(n);
             ND_HIP(hipMemcpy(h.data(), buf, n * 8, hipMemcpyDeviceToHost));
-            const char *names[6] = {"issue loads", "MFMA loop", "wait vmcnt", "transform+publish (inside the loop)", "epilogue", "barrier"};
+            const char *names[6] = {"issue loads + DMA", "MFMA loop", "wait vmcnt", "transform+publish (inside the loop)", "epilogue", "barrier"};
             for (int w : {0, 1, 4}) {
                 double tot[6] = {0}, steps = 0;
                 for (long b = 0; b < g2; ++b) {
