@@ -229,7 +229,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_w1d(ConvParams p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int m8 = ((mb * MTB + wm * MR + mr) * 32) + 8 * g;
-                const f32x8 b8 = sload8(p.bias + m8);
+                const f32x4 bq = sload_bias4(p.bias + m8, h);
                 const int m4 = m8 + 4 * h;
                 f32x4 yy[T];
                 combine(mr, g, yy);
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_w1d(ConvParams p) {
 #pragma unroll
                     for (int i = 0; i < T; ++i) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) yy[i][e] += h ? b8[4 + e] : b8[e];
+                        for (int e = 0; e < 4; ++e) yy[i][e] += bq[e];
                         if (pre && i < left) pre[i] = yy[i];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) yy[i][e] = apply_act(yy[i][e], p.act, slope);
