@@ -14,7 +14,7 @@ is fixed -> "strong".  `--frames F` is BASELINE configs[2]'s shape instead: F fr
 (frame-level sharding, no per-frame exchange; work per step is fixed by F, so more ranks finish a step sooner).
 
 One JSON line on rank 0:
-  roofline      the dominant kernel by time (conv_w1d, the fused 1-D Winograd 3x3 kernel on the fp32 path): MFMA-EXECUTED
+  roofline      the dominant kernel by time (conv_w2d, the fused 1-D Winograd 3x3 kernel on the fp32 path): MFMA-EXECUTED
                 FLOP / HIP-event time on the launch stream / MFMA peak (<= 1 by construction); the algorithmic
                 (direct-convolution) rate is reported beside it, and `families` prices every kernel family against its own
                 bound (transform passes against HBM)
@@ -204,7 +204,7 @@ def roofline_report(steps, dtype, cs, batch, funit):
         if s["form"] == "pool":
             add("k_maxpool2", "hbm", s["ms"], byts=s["bytes"])
         elif s["form"] in ("w1d_f43", "w1d_f23"):
-            add("conv_w1d (3x3, 1-D Winograd F(4,3) fused into the implicit GEMM)", "mfma", s["ms"], s["flop"], s["mfma_flop"], s["bytes"])
+            add("conv_w2d (3x3, 1-D Winograd F(4,3), input transform shared through LDS)", "mfma", s["ms"], s["flop"], s["mfma_flop"], s["bytes"])
         elif s["form"] == "wino3p_f4x4":
             if s["ms_gemm"] > 0:
                 add("conv_qp 1-tap (36 GEMMs of a three-pass Winograd F(4x4,3x3) layer)", "mfma", s["ms_gemm"], s["flop"], s["mfma_flop"],
@@ -233,8 +233,8 @@ def roofline_report(steps, dtype, cs, batch, funit):
     # the dominant kernel by time among the MFMA families
     dom = max((r for r in families if r["bound"] == "mfma"), key=lambda r: r["ms_per_batch"])
     f = fam[dom["kernel"]]
-    is_w1d = dom["kernel"].startswith("conv_w1d")
-    traffic = pmc_traffic("conv_w1d<", cs, batch, funit) if (is_w1d and dtype == "f32") else None
+    is_w2d = dom["kernel"].startswith("conv_w2d")
+    traffic = pmc_traffic("conv_w2d<", cs, batch, funit) if (is_w2d and dtype == "f32") else None
     stack_alg = sum(s["flop"] for s in conv) / (sum(s["ms"] for s in conv) * 1e-3) / 1e12
     stack_exe = sum(s["mfma_flop"] for s in conv) / (sum(s["ms"] for s in conv) * 1e-3) / 1e12
     return {

@@ -204,9 +204,12 @@ static int pick_variant(const ConvDesc &d, int M) {
             const int cus = g_num_cus > 0 ? g_num_cus : 256;
             double best = 0;
             int best_v = -1;
-            const struct { int v; double unit; } cand[] = {{0, 1.0}, {11, 0.955}};
+            // (16-bit storage: the MFMAs are 16x faster, the LDS-DMA stream per CU is the bound -> the 128 x 512 tile, 35 KB of DMA
+            // per 32k outputs against 42 (64 x 1024) and 52 (64 x 512), where the layer has 128 output channels to fill it)
+            const struct { int v; double unit; } cand[] = {{0, 1.0}, {11, dt == ND_F32 ? 0.955 : 0.85}, {14, dt == ND_F32 ? 2.0 : 0.72}};
             for (const auto &c : cand) {
                 const Variant &V = variant_at(g0 + c.v);
+                if (c.v == 14 && (M < 128 || dt == ND_F32)) continue;
                 bool cross = true;
                 if (variant_lds(V, d.in, &cross) > kMaxLds) continue;
                 const long pv = (long)Hv * Wv;

@@ -136,7 +136,14 @@ __global__ __launch_bounds__(512) void conv_w2d(ConvParams p) {
     // weight pieces (12 each) by LDS-DMA -- all of it while their SIMD partners already run MFMAs.
     int f_id = vb, f_c = 0, f_end = 0, f_stage = 0, issued = 0;
     const float *f_w;
-    const bool xfA = wave < 4, xfB = wave == 0;
+    // (role experiments: p.dbg bit 0 -> the younger waves 4..7 transform; bit 1 -> pass B on the other half's first wave;
+    //  bits 2..3 -> which waves issue the DMA: 0 = 1..3 (12 each), 1 = 5..7 (12 each), 2 = 4..7 (9 each), 3 = 0..3 (9 each))
+    const int xbase = (p.dbg & 1) ? 4 : 0;
+    const bool xfA = (wave >> 2) == (xbase >> 2), xfB = wave == ((p.dbg & 2) ? (xbase ^ 4) : xbase);
+    const int dma_mode = (p.dbg >> 2) & 3;
+    const int dma_first = dma_mode == 0 ? 1 : (dma_mode == 1 ? 5 : (dma_mode == 2 ? 4 : 0));
+    const int dma_per = dma_mode < 2 ? 12 : 9;
+    const int dma_idx = wave - dma_first;     // this wave issues pieces [dma_idx * dma_per, + dma_per) when 0 <= dma_idx < 36 / dma_per
     int vwOff[2];
     int x_h[2], x_i[2], x_s[2];
 #pragma unroll
@@ -208,11 +215,12 @@ __global__ __launch_bounds__(512) void conv_w2d(ConvParams p) {
     };
     auto fill_dma = [&]() {
         if (issued >= nsteps || (DBG & 4)) return;
-        if (wave >= 1 && wave < 4) {
+        if (dma_idx >= 0 && dma_idx * dma_per < 36) {
             // stage image of the weights = [M tile mt][plane]: piece q lives at mt = q / 18, plane q % 18 of K block f_c
 #pragma unroll
             for (int k = 0; k < 12; ++k) {
-                const int q = (wave - 1) * 12 + k;
+                if (k >= dma_per) break;
+                const int q = dma_idx * dma_per + k;
                 const int mt = q / kTaps, pl = q - mt * kTaps;
                 glds16(f_w + ((size_t)mt * p.KB + (size_t)f_c) * kTaps * 256 + pl * 256, smem + f_stage * kStage + q * 1024);
             }
@@ -573,6 +581,8 @@ int nd_launch_conv_w2d(const ConvDesc &d, hipStream_t stream) {
     p.cps = cps;
     p.nitems = (int)(first + (ntiles - first) * S);
     p.part = (f32x4 *)d.part;
+    static const int roles_env = getenv("ND_W2D_ROLES") ? atoi(getenv("ND_W2D_ROLES")) : 0;
+    p.dbg = roles_env;
     const long grid = p.nitems < slots ? p.nitems : slots;
     if (dbg_env == 128) {
         // stamped diagnostic launch: no split-K (p.part carries the stamp buffer), synchronous, prints the phase split per wave role
