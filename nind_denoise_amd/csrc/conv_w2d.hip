@@ -129,11 +129,10 @@ __global__ __launch_bounds__(512) void conv_w2d(ConvParams p) {
     };
 
     // ---- fill cursor: the (tile, K chunk) stream one step ahead of the MFMA loop.
-    // Who does the memory work matters: of the two waves of a SIMD the OLDER one (waves 0..3) wins the matrix pipe, finishes its
-    // 72 MFMAs first and then waits ~4,800 cycles at the step's barrier, while the younger one (waves 4..7) is the step's critical
-    // path (in-kernel stamps).  So waves 4..7 only multiply and store; waves 0..3 load and transform the
-    // pixels (pass A: 4 x 64 = 256 of the 320 lane-transforms, pass B: the other 64 on wave 0) and waves 1..3 issue the 36
-    // weight pieces (12 each) by LDS-DMA -- all of it while their SIMD partners already run MFMAs.
+    // Who does the memory work: of the two waves of a SIMD the one that starts its MFMAs first wins the matrix pipe, finishes its
+    // 72 MFMAs early and then waits ~4,800 cycles at the step's barrier; the other one is the step's critical path (in-kernel
+    // stamps).  One half of the waves (p.dbg bit 0: which) loads and transforms the pixels (pass A: 4 x 64 = 256
+    // of the 320 lane-transforms, pass B: the other 64 on one more wave), three waves issue the 36 weight pieces by LDS-DMA.
     int f_id = vb, f_c = 0, f_end = 0, f_stage = 0, issued = 0;
     const float *f_w;
     // (role experiments: p.dbg bit 0 -> the younger waves 4..7 transform; bit 1 -> pass B on the other half's first wave;
@@ -581,7 +580,9 @@ int nd_launch_conv_w2d(const ConvDesc &d, hipStream_t stream) {
     p.cps = cps;
     p.nitems = (int)(first + (ntiles - first) * S);
     p.part = (f32x4 *)d.part;
-    static const int roles_env = getenv("ND_W2D_ROLES") ? atoi(getenv("ND_W2D_ROLES")) : 0;
+    // default roles 1: the younger waves 4..7 load + transform the pixels, waves 1..3 issue the weight DMA (tools/w2d_roles.sh:
+    // the twelve assignments tried are within 3 % of each other, this one is 2 % ahead of "everything on the older waves")
+    static const int roles_env = getenv("ND_W2D_ROLES") ? atoi(getenv("ND_W2D_ROLES")) : 1;
     p.dbg = roles_env;
     const long grid = p.nitems < slots ? p.nitems : slots;
     if (dbg_env == 128) {

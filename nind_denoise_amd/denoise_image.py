@@ -170,8 +170,54 @@ def copy_exif(args):
     exiv_dst.writeMetadata()
 
 
+def _save_dbg_jpg(t, path):
+    """torchvision.utils.save_image semantics for one [3,h,w] float tensor: clamp to [0,1], * 255 + 0.5, uint8, PIL."""
+    from PIL import Image
+    arr = t.detach().float().clamp(0, 1).mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to('cpu', torch.uint8).numpy()
+    Image.fromarray(arr).save(path)
+
+
+def _denoise_frame_debug(model, ds, cs, ucs, overlap, batch, outpath):
+    """--debug (denoise_image.py:149-150, 260-269): the loop tile by tile with the reference's crop dumps in ./dbg --
+    crop<batch>_<i>_denoised.jpg (the network's whole output tile), _tensimg.jpg (useful crop with halved overlap strips),
+    _noisy.jpg (the input tile) -- and the last output tile with its borders as <output>dbg_inclborders.tif.  The canvas
+    is built by the same device stitch kernel as the fast path (identical result, just not fused)."""
+    os.makedirs('dbg', exist_ok=True)
+    img = ds.inimg
+    H, W = img.size(1), img.size(2)
+    canvas = torch.zeros_like(img)
+    last = None
+    for n_count, t0 in enumerate(range(0, len(ds), batch)):
+        cnt = min(batch, len(ds) - t0)
+        print(str(n_count) + '/' + str(int(len(ds) / batch)))
+        ybatch = pipeline.gather_tiles(img, cs, ucs, overlap, t0, cnt)
+        xbatch = model(ybatch)
+        pipeline.stitch_tiles(canvas, xbatch, cs, ucs, overlap, t0)
+        for i in range(cnt):
+            _, _, ud, us = _lib.tile_geom(t0 + i, W, H, cs, ucs, overlap)
+            absx0, absy0 = us
+            tensimg = xbatch[i][:, ud[1]:ud[3], ud[0]:ud[2]].clone()
+            if absx0 != 0:
+                tensimg[:, :, 0:overlap] /= 2
+            if absy0 != 0:
+                tensimg[:, 0:overlap, :] /= 2
+            if absx0 + ucs < W and overlap:
+                tensimg[:, :, -overlap:] /= 2
+            if absy0 + ucs < H and overlap:
+                tensimg[:, -overlap:, :] /= 2
+            _save_dbg_jpg(xbatch[i], 'dbg/crop' + str(n_count) + '_' + str(i) + '_denoised.jpg')
+            _save_dbg_jpg(tensimg, 'dbg/crop' + str(n_count) + '_' + str(i) + '_tensimg.jpg')
+            _save_dbg_jpg(ybatch[i], 'dbg/crop' + str(n_count) + '_' + str(i) + '_noisy.jpg')
+            print(tensimg.shape)
+            print((absx0, absy0, ud))
+            last = xbatch[i]
+    if last is not None:
+        pt_helpers.tensor_to_imgfile(last.clip(0, 1).cpu(), outpath + 'dbg_inclborders.tif')
+    return canvas
+
+
 def denoise_file(model, inpath, outpath, cs, ucs, overlap, batch=32, whole_image=False, pad=None, max_subpixels=None,
-                 device=None, verbose=True):
+                 device=None, verbose=True, debug=False):
     '''One image file through the device-resident crop -> infer -> stitch loop (the body of the reference's __main__,
     denoise_image.py:228-270); also what denoise_dir runs per image, in process, instead of spawning this script.'''
     ds = OneImageDS(inpath, cs, ucs, overlap, whole_image=whole_image, pad=pad, device=device)
@@ -192,7 +238,10 @@ def denoise_file(model, inpath, outpath, cs, ucs, overlap, batch=32, whole_image
         def progress(n, t0, cnt):
             if verbose:
                 print(str(n) + '/' + str(nbatches))
-        newimg = pipeline.denoise_frame(model, ds.inimg, cs, ucs, overlap, batch=batch, progress=progress)
+        if debug:
+            newimg = _denoise_frame_debug(model, ds, cs, ucs, overlap, batch, outpath)
+        else:
+            newimg = pipeline.denoise_frame(model, ds.inimg, cs, ucs, overlap, batch=batch, progress=progress)
     torch.cuda.synchronize()
     pt_helpers.tensor_to_imgfile(newimg.cpu(), outpath)
     return newimg
@@ -221,7 +270,7 @@ def main(argv=None):
     model = model.to(device)
     start_time = time.time()
     denoise_file(model, args.input, args.output, args.cs, args.ucs, args.overlap, batch=args.batch_size or 64,
-                 whole_image=args.whole_image, pad=args.pad, max_subpixels=args.max_subpixels, device=device)
+                 whole_image=args.whole_image, pad=args.pad, max_subpixels=args.max_subpixels, device=device, debug=args.debug)
     print(f'Denoised image written to {args.output}')
     copy_exif(args)
     print(f'Wrote denoised image to {args.output}')

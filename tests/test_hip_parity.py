@@ -552,6 +552,44 @@ def test_cli_end_to_end(dev, tmp_path):
     assert ud.dtype == torch.int32
 
 
+def test_cli_debug_crop_dumps(dev, tmp_path, monkeypatch):
+    # --debug (denoise_image.py:149-150, 260-269): per-tile crop dumps in ./dbg and the last tile with borders; the canvas is the
+    # same as without the flag
+    from PIL import Image
+    from nind_denoise_amd import denoise_image as di
+    from nind_denoise_amd.common.libs import imgcodec, np_imgops
+    from oracle import tiler as otiler
+    sd = synth.make_utnet_state_dict(funit=8, seed=21)
+    torch.save(sd, tmp_path / "generator_1.pt")
+    frame = synth.make_frame(200, 180, seed=9)
+    inp = str(tmp_path / "in.tif")
+    imgcodec.write_tiff(inp, np.ascontiguousarray(frame.transpose(1, 2, 0)))
+    monkeypatch.chdir(tmp_path)
+    common = ["--network", "UtNet", "--model_path", str(tmp_path / "generator_1.pt"), "--model_parameters", "funit=8", "--input", inp,
+              "--cs", "120", "--ucs", "88", "-ol", "16", "--exif_method", "noexif", "-b", "3"]
+    assert di.main(common + ["--output", str(tmp_path / "a.tiff")]) == 0
+    assert di.main(common + ["--output", str(tmp_path / "b.tiff"), "--debug"]) == 0
+    a, b = np_imgops.img_path_to_np_flt(str(tmp_path / "a.tiff")), np_imgops.img_path_to_np_flt(str(tmp_path / "b.tiff"))
+    assert np.abs(a - b).max() <= 1e-6
+    grid = otiler.TileGrid(200, 180, 120, 88, 16)
+    dumps = sorted(os.listdir(tmp_path / "dbg"))
+    assert len(dumps) == 3 * grid.size
+    n_last, i_last = (grid.size - 1) // 3, (grid.size - 1) % 3
+    noisy = np.asarray(Image.open(tmp_path / "dbg" / f"crop{n_last}_{i_last}_noisy.jpg"))
+    assert noisy.shape == (120, 120, 3)
+    want = (otiler.gather_tile(frame, grid, grid.size - 1).transpose(1, 2, 0) * 255 + 0.5).clip(0, 255).astype(np.uint8)
+    # JPEG of the mirrored input tile: the synthetic frame is pixel noise on a gradient (chroma subsampling smears the noise), so
+    # compare 8x8 block means of the luminance
+    def blocks(a):
+        y = a.astype(np.float64) @ np.array([0.299, 0.587, 0.114])
+        return y.reshape(15, 8, 15, 8).mean(axis=(1, 3))
+    assert np.abs(blocks(noisy) - blocks(want)).max() < 4
+    _, _, ud, _ = grid.geom(grid.size - 1)
+    tens = Image.open(tmp_path / "dbg" / f"crop{n_last}_{i_last}_tensimg.jpg")
+    assert tens.size == (ud[2] - ud[0], ud[3] - ud[1])
+    assert os.path.isfile(str(tmp_path / "b.tiff") + "dbg_inclborders.tif")
+
+
 @pytest.mark.parametrize("cs", [504, 520])
 def test_utnet_f64_wide_tiles_vs_oracle(dev, cs):
     # the shipped default tile (cs=504, denoise_image.py:41) and BASELINE config 4's cs=520: rows too wide for three
