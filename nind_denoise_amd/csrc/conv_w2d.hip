@@ -37,8 +37,15 @@ constexpr int kStage = kWBytes + kVBytes;
 constexpr int kStages = 2;
 constexpr int kScratch = 2048;                // per wave: epilogue transpose (8 rows x 16 pixels of one channel quad)
 constexpr int kLds = kStages * kStage + 8 * kScratch;   // 151,552 B
+constexpr int kDmaAt = 4;                     // waves 0..3 issue the next step's weight DMA after this many groups
 constexpr int kXfAt = 12;                     // the transform of the next step's pixels sits after this many (ky, position) groups
 constexpr int kSlots = 4 * 32 * 4;            // pixel slots of a tile in the split-K scratch: (wave column, lane, pixel)
+
+// LDS-DMA piece with an immediate offset (applied to the global AND the LDS address): 8 pieces of a contiguous run share one
+// address register and one M0
+template <int OFF> __device__ __forceinline__ void glds16o(const void *g, void *l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)l, 16, OFF, 0);
+}
 
 // slot of strip s in row r of a V plane: XOR-swizzled so that the 16 lanes of a ds_read_b128 group (4 strips x 4 rows of one wave)
 // hit 16 different bank quads without padding the rows
@@ -135,14 +142,12 @@ __global__ __launch_bounds__(512) void conv_w2d(ConvParams p) {
     // of the 320 lane-transforms, pass B: the other 64 on one more wave), three waves issue the 36 weight pieces by LDS-DMA.
     int f_id = vb, f_c = 0, f_end = 0, f_stage = 0, issued = 0;
     const float *f_w;
-    // (role experiments: p.dbg bit 0 -> the younger waves 4..7 transform; bit 1 -> pass B on the other half's first wave;
-    //  bits 2..3 -> which waves issue the DMA: 0 = 1..3 (12 each), 1 = 5..7 (12 each), 2 = 4..7 (9 each), 3 = 0..3 (9 each))
-    const int xbase = (p.dbg & 1) ? 4 : 0;
-    const bool xfA = (wave >> 2) == (xbase >> 2), xfB = wave == ((p.dbg & 2) ? (xbase ^ 4) : xbase);
-    const int dma_mode = (p.dbg >> 2) & 3;
-    const int dma_first = dma_mode == 0 ? 1 : (dma_mode == 1 ? 5 : (dma_mode == 2 ? 4 : 0));
-    const int dma_per = dma_mode < 2 ? 12 : 9;
-    const int dma_idx = wave - dma_first;     // this wave issues pieces [dma_idx * dma_per, + dma_per) when 0 <= dma_idx < 36 / dma_per
+    // Roles (tools/w2d_roles.sh tried twelve assignments: all within 3 % of each other): waves 4..7 load + transform the pixels
+    // (pass A), wave 0 pass B; waves 0..3 issue the weight DMA, 9 contiguous pieces each.
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const int kXfHalf = 1;   // which half of the waves transforms (1: waves 4..7 -- measured 5 % faster than the older half); the other half issues the DMA
+    const bool xfA = (wave >> 2) == kXfHalf, xfB = wave == 4 * (1 - kXfHalf);
+    const int dw = wave - 4 * (1 - kXfHalf);   // DMA wave index 0..3 (negative / >= 4: none)
     int vwOff[2];
     int x_h[2], x_i[2], x_s[2];
 #pragma unroll
@@ -153,19 +158,19 @@ __global__ __launch_bounds__(512) void conv_w2d(ConvParams p) {
         x_s[ps] = xt % kS;
         vwOff[ps] = kWBytes + x_h[ps] * kVPlane + vslot(x_i[ps], x_s[ps]) * 16;   // where this lane writes v[position 0]
     }
-    unsigned x_off[2] = {0, 0};   // float4 index of the lane's 6 input pixels inside the two-plane window of a K block
+    unsigned x_off[2] = {0, 0};   // byte offset of the lane's 6 input pixels inside the two-plane window of a K block (< 2^32)
     int x_keep[2] = {6, 6};       // inputs [0, keep) feed in-row outputs (6 unless the group hangs over the row end)
     auto set_fill_tile = [&](int w) {
         const Item it = decode(w);
         f_c = it.c0;
         f_end = it.c1;
         const int nb = it.tile / p.n_tiles_m, mb = it.tile - nb * p.n_tiles_m;
-        f_w = p.wpk + (size_t)mb * kMTB * p.KB * kTaps * 256 + lane * 4;
+        f_w = p.wpk + (size_t)mb * kMTB * p.KB * kTaps * 256;     // wave-uniform: the lane's 16 bytes are added as a 32-bit offset
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps)
             if (ps == 0 ? xfA : xfB) {
                 const Strip st = strip_of(nb, x_s[ps]);
-                x_off[ps] = (unsigned)x_h[ps] * (unsigned)p.in_plane + (unsigned)st.img * (unsigned)p.P + (unsigned)(st.y0 + x_i[ps]) * p.Wb + st.x0;
+                x_off[ps] = 16u * ((unsigned)x_h[ps] * (unsigned)p.in_plane + (unsigned)st.img * (unsigned)p.P + (unsigned)(st.y0 + x_i[ps]) * p.Wb + st.x0);
                 const int left = p.wpx - st.x0;
                 x_keep[ps] = left + 2 < 6 ? left + 2 : 6;
             }
@@ -183,15 +188,14 @@ __global__ __launch_bounds__(512) void conv_w2d(ConvParams p) {
     // priority -- DESIGN.md section 4.)
     auto fill_loads = [&]() {
         if (issued >= nsteps || (DBG & 8)) return;
+        const char *kbase = (const char *)(p.in + (size_t)(2 * f_c) * p.in_plane);   // scalar; x_off is a 32-bit BYTE offset
         if (xfA) {
-            const f32x4 *src = p.in + (size_t)(2 * f_c) * p.in_plane + x_off[0];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) dn[0][k] = src[k];
+            for (int k = 0; k < 6; ++k) dn[0][k] = *(const f32x4 *)(kbase + x_off[0] + 16 * k);
         }
         if (xfB) {
-            const f32x4 *src = p.in + (size_t)(2 * f_c) * p.in_plane + x_off[1];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) dn[1][k] = src[k];
+            for (int k = 0; k < 6; ++k) dn[1][k] = *(const f32x4 *)(kbase + x_off[1] + 16 * k);
         }
     };
     auto fill_xform = [&]() {
@@ -214,15 +218,23 @@ __global__ __launch_bounds__(512) void conv_w2d(ConvParams p) {
     };
     auto fill_dma = [&]() {
         if (issued >= nsteps || (DBG & 4)) return;
-        if (dma_idx >= 0 && dma_idx * dma_per < 36) {
-            // stage image of the weights = [M tile mt][plane]: piece q lives at mt = q / 18, plane q % 18 of K block f_c
-#pragma unroll
-            for (int k = 0; k < 12; ++k) {
-                if (k >= dma_per) break;
-                const int q = dma_idx * dma_per + k;
-                const int mt = q / kTaps, pl = q - mt * kTaps;
-                glds16(f_w + ((size_t)mt * p.KB + (size_t)f_c) * kTaps * 256 + pl * 256, smem + f_stage * kStage + q * 1024);
-            }
+        if (dw >= 0 && dw < 4) {
+            // stage image of the weights = [M tile mt][18 planes] of 1 KiB pieces; wave w copies planes [9 * (w & 1), + 9) of M tile
+            // w >> 1 of K block f_c: source and destination are both contiguous, so the 9 pieces need two address registers (one
+            // 64-bit add each) and immediate offsets -- with a 64-bit pointer computed per piece every piece cost ~4 VALU-slot
+            // instructions, each of which waits for a 64-cycle MFMA slot of the SIMD partner (12 pieces took 5,200 cycles)
+            const int mt = dw >> 1, pl0 = (dw & 1) * 9;
+            const char *src = (const char *)(f_w + (((size_t)mt * p.KB + (size_t)f_c) * kTaps + pl0) * 256) + lane16;
+            char *dst = smem + f_stage * kStage + (mt * kTaps + pl0) * 1024;
+            glds16o<-4096>(src + 4096, dst + 4096);
+            glds16o<-3072>(src + 4096, dst + 4096);
+            glds16o<-2048>(src + 4096, dst + 4096);
+            glds16o<-1024>(src + 4096, dst + 4096);
+            glds16o<0>(src + 4096, dst + 4096);
+            glds16o<1024>(src + 4096, dst + 4096);
+            glds16o<2048>(src + 4096, dst + 4096);
+            glds16o<3072>(src + 4096, dst + 4096);
+            glds16o<0>(src + 8192, dst + 8192);
         }
     };
     auto fill_advance = [&]() {
@@ -388,8 +400,7 @@ __global__ __launch_bounds__(512) void conv_w2d(ConvParams p) {
     unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;   // DBG & 128: cycles per phase, summed over the steps
     for (int s = 0; s < nsteps; ++s) {
         if (DBG & 128) t0 = stamp();
-        fill_loads();                       // next step's pixels and weights fly under this step's MFMAs
-        fill_dma();
+        fill_loads();                       // next step's pixels fly under this step's MFMAs (their weights: kDmaAt)
         __builtin_amdgcn_sched_barrier(0);
         if (DBG & 128) { t1 = stamp(); tph[0] += t1 - t0; t0 = t1; }
         const char *wa = smem + c_stage * kStage + aOff;
@@ -412,6 +423,14 @@ __global__ __launch_bounds__(512) void conv_w2d(ConvParams p) {
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[x][q] += a[st & 1][q] * b[st & 1][q];
+            }
+            if (st + 1 == kDmaAt) {
+                // the weight DMA of the next step goes out here, not at the top of the step: the CU's vector-memory path moves
+                // ~15 B/clk, so the step's 36 + 30 KiB of requests take ~4,500 cycles to issue -- the pixel loads, which gate the
+                // transforming waves, must not queue behind the 36 DMA pieces
+                __builtin_amdgcn_sched_barrier(0);
+                fill_dma();
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (st + 1 == kXfAt) {
                 // the raw pixels of the next step were requested at the top of this step: transform them here, inside this wave's
@@ -506,7 +525,7 @@ int nd_launch_conv_w2d(const ConvDesc &d, hipStream_t stream) {
     if (d.out_plane0 + d.cout / 4 > d.out.planes) ND_FAIL(ND_EINVAL, "w2d: destination planes overflow");
     // a lane's float4 index inside a K block's two-plane window is 32 bits; strips of the last band / group read up to 9 rows + 5
     // pixels past the last valid pixel (the buffers carry that slack)
-    if (2 * d.in.np() >= (1L << 32) || d.in.used() >= (1L << 31)) ND_FAIL(ND_EINVAL, "w2d: input too large for 32-bit indexing");
+    if (2 * d.in.np() * 16 + 65536 >= (1L << 32) || d.in.used() >= (1L << 31)) ND_FAIL(ND_EINVAL, "w2d: input too large for 32-bit byte offsets");
 
     static int cus[16] = {0}, lds_set[16] = {0};
     int dev = 0;
@@ -580,10 +599,6 @@ int nd_launch_conv_w2d(const ConvDesc &d, hipStream_t stream) {
     p.cps = cps;
     p.nitems = (int)(first + (ntiles - first) * S);
     p.part = (f32x4 *)d.part;
-    // default roles 1: the younger waves 4..7 load + transform the pixels, waves 1..3 issue the weight DMA (tools/w2d_roles.sh:
-    // the twelve assignments tried are within 3 % of each other, this one is 2 % ahead of "everything on the older waves")
-    static const int roles_env = getenv("ND_W2D_ROLES") ? atoi(getenv("ND_W2D_ROLES")) : 1;
-    p.dbg = roles_env;
     const long grid = p.nitems < slots ? p.nitems : slots;
     if (dbg_env == 128) {
         // stamped diagnostic launch: no split-K (p.part carries the stamp buffer), synchronous, prints the phase split per wave role
