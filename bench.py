@@ -160,11 +160,12 @@ def conv_stack_profile(net, cs, batch, dev, reps=3):
     return steps
 
 
-def pmc_traffic(kernel_prefix, cs, batch, funit):
-    """HBM bytes per launch of one kernel from the newest committed rocprofv3 PMC summary of the same configuration
+def pmc_traffic(kernel_regex, cs, batch, funit, dtype):
+    """HBM bytes per launch of one kernel family from the newest committed rocprofv3 PMC summary of the same configuration
     (FETCH_SIZE and WRITE_SIZE collected in separate passes, gfx950 read correction applied -- profiles/*_pmc_summary.json).
     Counters cannot be read inside the timed run, so the figure comes from a stored profile and says so; None otherwise."""
     import glob
+    import re
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), reverse=True):
         try:
             with open(f) as fh:
@@ -172,11 +173,11 @@ def pmc_traffic(kernel_prefix, cs, batch, funit):
         except (OSError, ValueError):
             continue
         c = d.get("config", {})
-        if (c.get("cs"), c.get("tiles_per_launch"), c.get("funit")) != (cs, batch, funit):
+        if (c.get("cs"), c.get("tiles_per_launch"), c.get("funit"), c.get("dtype", "f32")) != (cs, batch, funit, dtype):
             continue
         rd = wr = n = 0
         for name, v in d.get("kernels", {}).items():
-            if name.startswith(kernel_prefix) and "hbm_read_bytes_mean" in v and "hbm_write_bytes_mean" in v:
+            if re.match(kernel_regex, name) and "hbm_read_bytes_mean" in v and "hbm_write_bytes_mean" in v:
                 k = v["FETCH_SIZE"]["dispatches"]
                 rd += v["hbm_read_bytes_mean"] * k
                 wr += v["hbm_write_bytes_mean"] * k
@@ -233,8 +234,16 @@ def roofline_report(steps, dtype, cs, batch, funit):
     # the dominant kernel by time among the MFMA families
     dom = max((r for r in families if r["bound"] == "mfma"), key=lambda r: r["ms_per_batch"])
     f = fam[dom["kernel"]]
-    is_w2d = dom["kernel"].startswith("conv_w2d")
-    traffic = pmc_traffic("conv_w2d<", cs, batch, funit) if (is_w2d and dtype == "f32") else None
+    dt_idx = {"f32": 0, "bf16": 1, "f16": 2}[dtype]
+    if dom["kernel"].startswith("conv_w2d"):
+        rx = r"conv_w2d<"
+    elif dom["kernel"].startswith("conv_qp direct 3x3"):
+        rx = rf"conv_qp<{dt_idx}, \d, \d, \d, \d, 9, "
+    elif dom["kernel"].startswith("conv_qp 1-tap"):
+        rx = rf"conv_qp<{dt_idx}, \d, \d, \d, \d, 1, \d, false"
+    else:
+        rx = r"$^"
+    traffic = pmc_traffic(rx, cs, batch, funit, dtype)
     stack_alg = sum(s["flop"] for s in conv) / (sum(s["ms"] for s in conv) * 1e-3) / 1e12
     stack_exe = sum(s["mfma_flop"] for s in conv) / (sum(s["ms"] for s in conv) * 1e-3) / 1e12
     return {
