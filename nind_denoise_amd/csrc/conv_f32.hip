@@ -1,4 +1,6 @@
 // fp32 instantiations of the convolution kernel + variant table and launch code for every storage type
+#include <vector>
+
 #include "conv_qp.inc"
 
 // ------------------------------------------------------------------ variants and dispatch
@@ -344,6 +346,41 @@ int nd_launch_conv(const ConvDesc &d, hipStream_t stream) {
     p.nitems = (int)(sp.first + (ntiles - sp.first) * sp.S);
     p.part = (f32x4 *)d.part;
     const long grid = p.nitems < slots ? p.nitems : slots;
+#ifdef ND_QP_STAMPS
+    static const int dbg_env = getenv("ND_QP_DBG") ? atoi(getenv("ND_QP_DBG")) : 0;
+    if (dbg_env & 128) {
+        // stamped diagnostic launch: no split-K (p.part carries the stamp buffer), synchronous, prints the phase split of two waves
+        static unsigned long long *buf = nullptr;
+        const size_t n = (size_t)slots * 8 * 8;
+        if (!buf) ND_HIP(hipMalloc(&buf, n * 8));
+        ND_HIP(hipMemsetAsync(buf, 0, n * 8, stream));
+        p.dbg = dbg_env;
+        p.split_first = (int)ntiles; p.S = 1; p.cps = KB / V.kbc; p.nitems = (int)ntiles; p.part = (f32x4 *)buf;
+        const long g2 = ntiles < slots ? ntiles : slots;
+        hipLaunchKernelGGL(V.fn, dim3((unsigned)g2), dim3(V.threads), lds, stream, p);
+        ND_HIP(hipStreamSynchronize(stream));
+        static int printed = 0;
+        if (printed++ < 40) {
+            std::vector<unsigned long long> h(n);
+            ND_HIP(hipMemcpy(h.data(), buf, n * 8, hipMemcpyDeviceToHost));
+            const char *names[5] = {"barrier", "issue DMA", "MFMA loop", "wait vmcnt", "epilogue+next"};
+            fprintf(stderr, "[qp stamps] %s cin %d M %d tiles %ld chunks %d G %d\n", V.name, d.cin, M, ntiles, KB / V.kbc, p.G);
+            for (int w : {0, V.threads / 64 - 1}) {
+                double tot[5] = {0}, steps = 0;
+                for (long b = 0; b < g2; ++b) {
+                    for (int k = 0; k < 5; ++k) tot[k] += (double)h[((size_t)b * 8 + w) * 8 + k];
+                    steps += (double)h[((size_t)b * 8 + w) * 8 + 6];
+                }
+                double sum = 0;
+                for (int k = 0; k < 5; ++k) sum += tot[k];
+                fprintf(stderr, "   wave %d: %.0f cycles/step:", w, sum / steps);
+                for (int k = 0; k < 5; ++k) fprintf(stderr, "  %s %.0f (%.1f%%)", names[k], tot[k] / steps, 100 * tot[k] / sum);
+                fprintf(stderr, "\n");
+            }
+        }
+        return ND_OK;
+    }
+#endif
     hipLaunchKernelGGL(V.fn, dim3((unsigned)grid), dim3(V.threads), lds, stream, p);
     if (sp.first < ntiles)
         hipLaunchKernelGGL(k_split_finish, dim3((unsigned)(ntiles - sp.first), V.mblk / 4), dim3(256), 0, stream, p, V.mblk,

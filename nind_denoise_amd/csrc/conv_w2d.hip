@@ -304,6 +304,12 @@ __global__ __launch_bounds__(512) void conv_w2d(ConvParams p) {
         const bool okA = okx && st.y0 + e_row < p.Hv, okB = okx && st.y0 + e_row + 4 < p.Hv;
         const int q0 = (mb * kMTB + wm) * 8;                        // first channel quad of this wave's M tile
         const f32x2 slope2 = {slope, slope};
+        // fused MaxPool2d(2): the lanes with (lane & 2) == 0 each own one pooled pixel of the wave's 8 rows x 16 pixels -- pooled
+        // row e_row, pooled pixel e_px & 1 of the strip the lane already decoded (strips start on rows = 0 mod 8, pixels = 0 mod 4)
+        const int pp_i = (e_px & ~3) + 2 * (e_px & 1);              // scratch column of the 2x2 block's first pixel
+        const int pxp = (st.x0 >> 1) + (e_px & 1), pyp = (st.y0 >> 1) + e_row;
+        const bool okP = p.pool && !(lane & 2) && st.ok && 2 * pxp + 1 < p.wpx && 2 * pyp + 1 < p.Hv;
+        const unsigned offP = (unsigned)((st.img * p.pool_P + (pyp + p.pool_pad) * p.pool_W + pxp + p.pool_pad) * 16);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             f32x4 yy[4];
@@ -361,6 +367,13 @@ __global__ __launch_bounds__(512) void conv_w2d(ConvParams p) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const f32x4 va = *((const f32x4 *)scratch + e_row * 16 + e_px);
                 const f32x4 vb2 = *((const f32x4 *)scratch + (e_row + 4) * 16 + e_px);
+                f32x4 vp = va;
+                if (p.pool) {   // wave-uniform
+                    const f32x4 *blk = (const f32x4 *)scratch + (2 * e_row) * 16 + pp_i;
+                    const f32x4 p00 = blk[0], p01 = blk[1], p10 = blk[16], p11 = blk[17];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) vp[e] = fmaxf(fmaxf(p00[e], p01[e]), fmaxf(p10[e], p11[e]));
+                }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -369,6 +382,7 @@ __global__ __launch_bounds__(512) void conv_w2d(ConvParams p) {
                     char *pb = (char *)(p.out + (size_t)(p.out_plane0 + quad) * p.out_plane);   // wave-uniform plane base
                     if (okA) *(f32x4 *)(pb + offA) = va;
                     if (okB) *(f32x4 *)(pb + offB) = vb2;
+                    if (okP) *(f32x4 *)((char *)(p.pool + (size_t)quad * p.pool_plane) + offP) = vp;
                 }
             }
         }
@@ -586,12 +600,24 @@ int nd_launch_conv_w2d(const ConvDesc &d, hipStream_t stream) {
     p.act = d.act;
     p.slope = d.slope;
     p.slope_dev = d.slope_dev;
+    if (d.pool) {
+        const QpBuf &q = *d.pool;
+        if (q.dt != ND_F32 || q.B != d.in.B || q.Hb - 2 * q.pad != Hv / 2 || q.Wb - 2 * q.pad != Wpx / 2 || q.planes < d.cout / 4)
+            ND_FAIL(ND_EINVAL, "w2d: pooled destination does not fit %dx%dx%d", d.cout, Hv / 2, Wpx / 2);
+        if (q.used() * 16 >= (1L << 32)) ND_FAIL(ND_EINVAL, "w2d: pooled destination too large for 32-bit byte offsets");
+        p.pool = (f32x4 *)q.base;
+        p.pool_plane = q.np();
+        p.pool_P = q.Hb * q.Wb;
+        p.pool_W = q.Wb;
+        p.pool_pad = q.pad;
+    }
     p.n_tiles_n = (int)(((long)p.nimg * p.PV + kS - 1) / kS);
     p.n_tiles_m = (d.cout + kMTB * 32 - 1) / (kMTB * 32);
     p.tiles_per_problem = p.n_tiles_n * p.n_tiles_m;
     const long ntiles = p.tiles_per_problem;
     const long slots = cus[dev];
-    const long cap = d.part && !d.nosplit ? (long)(d.part_bytes / ((size_t)kMTB * 32 * kSlots * 4)) : 0;
+    // (a layer with a fused pool keeps every tile whole: the split-K finish kernel has no view of a tile's 2x2 neighbours)
+    const long cap = d.part && !d.nosplit && !d.pool ? (long)(d.part_bytes / ((size_t)kMTB * 32 * kSlots * 4)) : 0;
     int first, S, cps;
     nd_plan_split(ntiles, KB, slots, cap, &first, &S, &cps);
     p.split_first = first;

@@ -69,6 +69,9 @@ struct ConvDesc {
     int nbatch = 1;         // independent problems of this shape in one launch (Winograd positions)
     long in_bs = 0, out_bs = 0;   // 16-byte elements between consecutive problems' input / output buffers
     size_t w_bs = 0;        // floats between consecutive problems' packed weights (the bias is shared)
+    // fused MaxPool2d(2) (fp32 inference, conv_w2d.hip / winograd.hip): the layer also writes max over 2x2 blocks of its activated
+    // output into planes [0, cout/4) of `pool` (UtNet.py:99-105: every pooled tensor is a conv output that is also a skip)
+    const QpBuf *pool = nullptr;
 };
 // scratch that lets every layer split its partial round: 512 work items of 64 x 1024 accumulators
 static const size_t kSplitScratchBytes = (size_t)512 * 64 * 1024 * 4;

@@ -270,10 +270,16 @@ int run_stack(int f, int act, int dt, const float *blob, const Plan &pl, hipStre
     const BlobLayout bl = blob_layout(f, dt, pre == nullptr, pre != nullptr);
     const int cpp = nd_cpp(dt);
     int si = 0;
+    bool pool_done = false;   // the previous layer wrote the pooled tensor itself
+    QpBuf pool_view;
     for (const Step &st : kSteps) {
         if (ev) ND_HIP(hipEventRecord(ev[si], s));
         const int this_step = si++;
         if (st.layer < 0) {
+            if (pool_done) {
+                pool_done = false;
+                continue;
+            }
             // pool reads the skip half of the concat buffer: planes [mul*f/4, 2*mul*f/4)
             ND_TRY(nd_launch_maxpool2(pl.buf[st.src], st.dst_plane0_mul * f / cpp, st.dst_plane0_mul * f / cpp, pl.buf[st.dst], s));
             continue;
@@ -300,6 +306,15 @@ int run_stack(int f, int act, int dt, const float *blob, const Plan &pl, hipStre
         d.part_bytes = kSplitScratchBytes;
         d.nosplit = (flags & ND_FLAG_NO_SPLITK) != 0;
         const Form form = step_form(st, f, dt, flags, pl, bl, pre != nullptr, train_w1);
+        // MaxPool2d(2) fused into the producing layer's epilogue where its kernel can (conv_w2d, three-pass output transform):
+        // the pool kernel re-read the whole skip tensor from HBM (2.4 % of the fp32 conv stack)
+        const bool next_is_pool = this_step + 1 < kNumSteps && kSteps[this_step + 1].layer < 0;
+        const bool w2d = form == FORM_W1D4 && !pre && !(flags & ND_FLAG_W1D_REGS);
+        if (next_is_pool && !pre && (w2d || form == FORM_WINO3P)) {
+            pool_view = pl.buf[kSteps[this_step + 1].dst];
+            d.pool = &pool_view;
+            pool_done = true;
+        }
         if (form == FORM_W1D4 || form == FORM_W1D2) {
             // narrow layer: 1-D Winograd along x inside the implicit-GEMM kernel; F(4,3), or F(2,3) on rows too wide for it
             const int T = form == FORM_W1D4 ? kW1dTile : 2;
@@ -321,6 +336,13 @@ int run_stack(int f, int act, int dt, const float *blob, const Plan &pl, hipStre
                 c.in.B = c.out.B = nimg - b0 < kWinoChunk ? nimg - b0 : kWinoChunk;
                 c.in.base = d.in.base + (size_t)b0 * d.in.Hb * d.in.Wb * 4;
                 c.out.base = d.out.base + (size_t)b0 * d.out.Hb * d.out.Wb * 4;
+                QpBuf pv;
+                if (d.pool) {
+                    pv = *d.pool;
+                    pv.B = c.in.B;
+                    pv.base = d.pool->base + (size_t)b0 * pv.Hb * pv.Wb * 4;
+                    c.pool = &pv;
+                }
                 // (profiling: the split of a layer's time into its passes is recorded for a single-chunk layer only)
                 ND_TRY(nd_launch_conv_wino(kWinoTile, c, pl.wino, pl.wino_bytes, s, (ev_x && nimg <= kWinoChunk) ? ev_x + 2 * this_step : nullptr));
             }

@@ -110,7 +110,8 @@ template <int T>
 __global__ __launch_bounds__(128) void k_wino_output(const f32x4 *__restrict__ m, long mnp, long mbs, int B, int TY, int TX, int Hv,
                                                      int Wv, const float *__restrict__ bias, int act, float slope_imm,
                                                      const float *__restrict__ slope_dev, f32x4 *__restrict__ out, long onp,
-                                                     int out_plane0, int Ho, int Wo, int opad) {
+                                                     int out_plane0, int Ho, int Wo, int opad, f32x4 *__restrict__ pool, long pnp,
+                                                     int Hp, int Wp, int ppad) {
     constexpr int A = Wino<T>::A;
     constexpr int NT = 128;
     __shared__ f32x4 sm[T][NT * T];
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(128) void k_wino_output(const f32x4 *__restrict__ m
     const float slope = act == ND_ACT_NONE ? 1.f : (slope_dev ? *slope_dev : slope_imm);
     if (t < tiles) {
         const f32x4 *src = m + (long)q * mnp + t;
-        f32x4 r[A][T];
+        f32x4 r[A][T], yv[T][T];
 #pragma unroll
         for (int i = 0; i < A; ++i) {
             f32x4 row[A];
@@ -149,7 +150,25 @@ __global__ __launch_bounds__(128) void k_wino_output(const f32x4 *__restrict__ m
                     }
                 }
                 sm[i][threadIdx.x * T + j] = y;
+                yv[i][j] = y;
             }
+        }
+        if (pool) {   // fused MaxPool2d(2): a tile's T x T outputs hold (T/2)^2 whole 2x2 blocks (T even, tiles start on even pixels)
+            const int tx = (int)(t % TX), ty = (int)((t / TX) % TY), b = (int)(t / ((long)TX * TY));
+            f32x4 *pd = pool + (long)q * pnp + (long)b * Hp * Wp;
+#pragma unroll
+            for (int a = 0; a < T / 2; ++a)
+#pragma unroll
+                for (int c = 0; c < T / 2; ++c) {
+                    const int py = ty * (T / 2) + a, px = tx * (T / 2) + c;
+                    if (2 * py + 1 < Hv && 2 * px + 1 < Wv) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            v[e] = fmaxf(fmaxf(yv[2 * a][2 * c][e], yv[2 * a][2 * c + 1][e]), fmaxf(yv[2 * a + 1][2 * c][e], yv[2 * a + 1][2 * c + 1][e]));
+                        pd[(long)(py + ppad) * Wp + px + ppad] = v;
+                    }
+                }
         }
     }
     __syncthreads();
@@ -319,12 +338,25 @@ int nd_launch_conv_wino(int T, const ConvDesc &d, void *scratch, size_t scratch_
     const float *bias = d.wpk + (size_t)P * gemm_floats(d.cin, d.cout);
     dim3 go((unsigned)((g.tiles + 127) / 128), out_planes);
     f32x4 *out = (f32x4 *)d.out.base;
+    f32x4 *pool = nullptr;
+    long pnp = 0;
+    int Hp = 0, Wp = 0, ppad = 0;
+    if (d.pool) {
+        const QpBuf &q = *d.pool;
+        if (q.dt != ND_F32 || q.B != d.in.B || q.Hb - 2 * q.pad != g.Hv / 2 || q.Wb - 2 * q.pad != g.Wv / 2 || q.planes < out_planes)
+            ND_FAIL(ND_EINVAL, "winograd: pooled destination does not fit %dx%dx%d", d.cout, g.Hv / 2, g.Wv / 2);
+        pool = (f32x4 *)q.base;
+        pnp = q.np();
+        Hp = q.Hb;
+        Wp = q.Wb;
+        ppad = q.pad;
+    }
     if (T == 2)
         hipLaunchKernelGGL(k_wino_output<2>, go, dim3(128), 0, s, (const f32x4 *)m, g.mnp, g.mbs, d.in.B, g.TY, g.TX, g.Hv, g.Wv, bias,
-                           d.act, d.slope, d.slope_dev, out, d.out.np(), d.out_plane0, d.out.Hb, d.out.Wb, d.out.pad);
+                           d.act, d.slope, d.slope_dev, out, d.out.np(), d.out_plane0, d.out.Hb, d.out.Wb, d.out.pad, pool, pnp, Hp, Wp, ppad);
     else
         hipLaunchKernelGGL(k_wino_output<4>, go, dim3(128), 0, s, (const f32x4 *)m, g.mnp, g.mbs, d.in.B, g.TY, g.TX, g.Hv, g.Wv, bias,
-                           d.act, d.slope, d.slope_dev, out, d.out.np(), d.out_plane0, d.out.Hb, d.out.Wb, d.out.pad);
+                           d.act, d.slope, d.slope_dev, out, d.out.np(), d.out_plane0, d.out.Hb, d.out.Wb, d.out.pad, pool, pnp, Hp, Wp, ppad);
     ND_HIP(hipGetLastError());
     return ND_OK;
 }
