@@ -7,11 +7,13 @@
 A "step" is one 6000x4000 frame through the device-resident crop -> UtNet -> stitch loop (BASELINE.json configs[1],
 geometry "G24" of SURVEY.md section 8: cs=264 is the valid tile size nearest to the named 256, which the reference
 network itself rejects).  The frame is resident in HBM when the timed region starts and the stitched canvas is in HBM when
-it ends.  With N > 1 the tile index range of every frame is split into N contiguous shards (one rank per GPU); inside the
-timed region rank 0 sends every rank the image rows its shard reads (RCCL point-to-point over xGMI), every rank denoises its
-shard into its own canvas and rank 0 receives and adds the canvas row bands (nind_denoise_amd/dist.py): total work per step
-is fixed -> "strong".  `--frames F` is BASELINE configs[2]'s shape instead: F frames per step dealt round-robin to the ranks
-(frame-level sharding, no per-frame exchange; work per step is fixed by F, so more ranks finish a step sooner).
+it ends.  With N > 1 the path shards by FRAME (frames are independent; no data-path collective): a step is N frames, one per
+rank, every rank runs the whole loop on its own frame -> per-GPU work is fixed as N grows, "scaling": "weak", value = all
+ranks' megapixels / max-over-ranks time.  `--frames F` fixes the step at F frames dealt round-robin to the ranks (BASELINE
+configs[2]'s shape; "strong" over the batch).  `--tile-shard` is the single-frame latency mode: the tile index range of ONE
+frame is split into N contiguous shards; inside the timed region rank 0 sends every rank the image rows its shard reads (RCCL
+point-to-point over xGMI), every rank denoises its shard into its own canvas and rank 0 receives and adds the canvas row bands
+(nind_denoise_amd/dist.py): total work per step is fixed -> "strong".
 
 One JSON line on rank 0:
   roofline      the dominant kernel by time (conv_w2d, the fused 1-D Winograd 3x3 kernel on the fp32 path): MFMA-EXECUTED
@@ -84,6 +86,9 @@ def parse():
     ap.add_argument("--frames", type=int, default=0,
                     help="> 0: BASELINE configs[2]'s shape -- a step is this many frames, dealt round-robin to the ranks "
                          "(frame-level sharding, no per-frame exchange)")
+    ap.add_argument("--tile-shard", action="store_true",
+                    help="N > 1: split ONE frame's tiles over the ranks (single-frame latency, strong scaling, P2P row-band exchange) "
+                         "instead of one frame per rank")
     ap.add_argument("--cpu-sample-tiles", type=int, default=0, help="0: sized for ~10 s of CPU work per mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-winograd", action="store_true", help="direct convolution on every layer (A/B switch)")
@@ -347,6 +352,9 @@ def main():
     def compute(fr, cv, a, b):
         pipeline.denoise_frame(net, fr, cs, ucs, ol, batch=args.batch, tile_range=(a, b), canvas=cv)
 
+    weak = world > 1 and args.frames == 0 and not args.tile_shard
+    if weak:
+        args.frames = world   # one frame per rank per step: per-GPU work fixed as N grows
     if args.frames > 0:
         # configs[2] shape: a step = `frames` frames, frame f handled by rank f % world; a few distinct synthetic frames
         # resident in HBM are cycled (the arithmetic does not depend on the pixel values)
@@ -416,7 +424,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 3),
         "higher_is_better": True,
-        "scaling": "strong",
+        "scaling": "weak" if (weak or world == 1) else "strong",
         "vs_baseline": None,
         "dtype": args.dtype,
         "data": "synthetic" + (" -- REHEARSAL: all ranks on one GPU over gloo, not a benchmark result" if REHEARSAL else ""),
