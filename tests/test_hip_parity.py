@@ -1011,7 +1011,7 @@ def test_training_step_ssim_losses_vs_autograd(dev, cs, weights):
     params32 = _autograd_reference(sd, x, t, weights.get("L1", 0.0), weights.get("MSE", 0.0), **kw)[2]
     assert_close(y, y_ref.float(), "training forward")
     assert abs(loss.item() - loss_ref.item()) <= 2e-5 * max(1.0, abs(loss_ref.item())), (loss.item(), loss_ref.item())
-    worst = 0.0
+    worst, worst_of = 0.0, (0.0, 0.0, "")
     gmax = max(p.grad.abs().max().item() for p in params.values())
     assert gmax > 1e-4                                                        # a real gradient, not the relu-dead case
     for name, p in params.items():
@@ -1021,10 +1021,16 @@ def test_training_step_ssim_losses_vs_autograd(dev, cs, weights):
         worst = max(worst, err)
         # reference = float64 autograd, fixed bars at ~2x what was measured (mixed loss 7e-4, MS-SSIM alone 7.5e-3: the SSIM
         # gradient oscillates in sign from pixel to pixel, so whole-image sums -- PReLU slopes, biases -- keep few digits in
-        # fp32; fp32 autograd itself is params32 away from float64 on the same tensors)
+        # fp32; fp32 autograd itself is params32 away from float64 on the same tensors.  Measured on the worst parameter of
+        # the MS-SSIM case, the PReLU slope tconvs4.3.weight: HIP 6.2e-3, torch fp32 autograd 6.3e-3 -- the error is the
+        # conditioning of the sum in fp32, not the order of the five-scale product in nd_ssim_loss_grad)
         bar = 1.5e-2 if set(weights) == {"MSSSIM"} else 2e-3
-        assert torch.isfinite(got).all() and err <= bar, (name, err, bar, scale, (params32[name].grad - ref).abs().max().item() / scale)
-    print(f"training step {weights} cs{cs}: worst relative gradient error {worst:.2e}")
+        err32 = (params32[name].grad - ref).abs().max().item() / scale       # torch's own fp32 autograd against float64
+        if err > worst_of[0]:
+            worst_of = (err, err32, name)
+        assert torch.isfinite(got).all() and err <= bar, (name, err, bar, scale, err32)
+    print(f"training step {weights} cs{cs}: worst relative gradient error {worst:.2e} ({worst_of[2]}; torch fp32 autograd on the "
+          f"same parameter: {worst_of[1]:.2e})")
     if "MSSSIM" in weights:
         with pytest.raises(ValueError, match="161"):     # the 128 / 136-pixel crops of BASELINE config 5 cannot use MS-SSIM
             tr.forward_backward(x[..., :136, :136].contiguous(), t[..., :136, :136].contiguous())
