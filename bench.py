@@ -208,7 +208,9 @@ def roofline_report(steps, dtype, cs, batch, funit):
 
     for s in steps:
         if s["form"] == "pool":
-            add("k_maxpool2", "hbm", s["ms"], byts=s["bytes"])
+            # (fp32 default path: MaxPool2d(2) is fused into the producing layer's epilogue -- no launch, no time of its own)
+            if s["ms"] > 0.02:
+                add("k_maxpool2", "hbm", s["ms"], byts=s["bytes"])
         elif s["form"] in ("w1d_f43", "w1d_f23"):
             add("conv_w2d (3x3, 1-D Winograd F(4,3), input transform shared through LDS)", "mfma", s["ms"], s["flop"], s["mfma_flop"], s["bytes"])
         elif s["form"] == "wino3p_f4x4":
