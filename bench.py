@@ -89,7 +89,9 @@ def parse():
     ap.add_argument("--tile-shard", action="store_true",
                     help="N > 1: split ONE frame's tiles over the ranks (single-frame latency, strong scaling, P2P row-band exchange) "
                          "instead of one frame per rank")
-    ap.add_argument("--cpu-sample-tiles", type=int, default=0, help="0: sized for ~10 s of CPU work per mode")
+    ap.add_argument("--cpu-sample-tiles", type=int, default=0,
+                    help="0: sized for ~10 s of CPU work per mode; -1: the WHOLE frame, un-extrapolated (minutes: for a kept record)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads of the baseline leg (0: all the cgroup allows, max 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-winograd", action="store_true", help="direct convolution on every layer (A/B switch)")
     ap.add_argument("--no-roofline", action="store_true")
@@ -471,8 +473,10 @@ def main():
             del eng
             log("host-to-host leg done")
         if not args.no_cpu_baseline and world == 1:
-            threads = min(host_cores(), 64)
+            threads = args.cpu_threads or min(host_cores(), 64)
             n = args.cpu_sample_tiles or max(8, min(200, threads * 6))   # ~10 s of CPU work per mode at ~0.1 s/tile
+            if n < 0:
+                n = total
             ids = [int(i) for i in np.linspace(0, total - 1, n)]
             log(f"cpu baseline: {n} tiles on {threads} threads, grad mode then no_grad")
             cdt_g, _, tot = cpu_baseline(frame_np, sd, cs, ucs, ol, ids, threads, True)
@@ -483,8 +487,9 @@ def main():
                 "unit": "MP/s",
                 "cores": threads,
                 "kind": "port",
-                "sample": f"{n} of {tot} tiles of the same frame through oracle gather -> UtNet (torch CPU fp32, {threads} threads) -> stitch, "
-                          f"scaled by tiles; grad mode as the reference runs (denoise_image.py:246, no no_grad) in {cdt_g:.2f} s",
+                "sample": (f"the whole frame, un-extrapolated: all {tot} tiles" if n == tot else f"{n} of {tot} tiles of the same frame")
+                          + f" through oracle gather -> UtNet (torch CPU fp32, {threads} threads) -> stitch" + ("" if n == tot else ", scaled by tiles")
+                          + f"; grad mode as the reference runs (denoise_image.py:246, no no_grad) in {cdt_g:.2f} s",
                 "no_grad": {"value": round(mp * (n / tot) / cdt_n, 5), "seconds": round(cdt_n, 2)},
             }
             # parity of the timed HIP path on those same tiles (the launch shape of the timed loop: `batch` tiles per launch)
