@@ -119,6 +119,11 @@ int main(int argc, char **argv) {
             run<K_STORE, 8>("store", waves, win, iters, src, dst, cyc, sink, cus, mhz);
         }
     }
+    printf("-- few CUs active: is the store / HBM-stream rate a per-CU limit or the chip's?\n");
+    for (int ncu : {8, 32, 64, 128, 256}) {
+        run<K_STORE, 8>("store", 8, 64, 64, src, dst, cyc, sink, ncu, mhz);
+        run<K_LOAD, 8>("load", 8, 4096, 2, src, dst, cyc, sink, ncu, mhz);
+    }
     printf("-- operand sharing inside an XCD (one window set per `share` workgroups of the same XCD)\n");
     for (int share : {1, 4, 32})
         for (int rot : {0, 5})
