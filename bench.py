@@ -215,9 +215,9 @@ def roofline_report(steps, dtype, cs, batch, funit):
                 add("k_maxpool2", "hbm", s["ms"], byts=s["bytes"])
         elif s["form"] in ("w1d_f43", "w1d_f23"):
             add("conv_w2d (3x3, 1-D Winograd F(4,3), input transform shared through LDS)", "mfma", s["ms"], s["flop"], s["mfma_flop"], s["bytes"])
-        elif s["form"] == "wino3p_f4x4":
+        elif s["form"] == "wino3p_f6x6":
             if s["ms_gemm"] > 0:
-                add("conv_qp 1-tap (36 GEMMs of a three-pass Winograd F(4x4,3x3) layer)", "mfma", s["ms_gemm"], s["flop"], s["mfma_flop"],
+                add("conv_qp 1-tap (64 GEMMs of a three-pass Winograd F(6x6,3x3) layer)", "mfma", s["ms_gemm"], s["flop"], s["mfma_flop"],
                     s["xform_bytes_in"] + s["xform_bytes_out"] - s["bytes"])
                 add("k_wino_input + k_wino_output (transform passes)", "hbm", s["ms_xform_in"] + s["ms_xform_out"],
                     byts=s["xform_bytes_in"] + s["xform_bytes_out"], launches=2)

@@ -57,7 +57,7 @@ typedef enum nd_flags {
     ND_FLAG_NO_SPLITK = 1,    /* keep every output tile whole: no split-K tail, so a tile's bits do not depend on which other
                                  tiles share its launch (the default splits the K loop of a launch's last, partial round of
                                  workgroups over the idle CUs: deterministic, but fp32 sums re-associate by <= 1e-5)        */
-    ND_FLAG_DIRECT_CONV = 2,  /* direct convolution on every 3x3 layer (default on the fp32 path: Winograd F(4x4,3x3) from
+    ND_FLAG_DIRECT_CONV = 2,  /* direct convolution on every 3x3 layer (default on the fp32 path: Winograd F(6x6,3x3) from
                                  128 channels up, 1-D F(4,3) inside the implicit-GEMM kernel below; ~1e-5 re-association)   */
     ND_FLAG_W1D_REGS = 4      /* A/B switch: the 1-D F(4,3) layers through the kernel that transforms in registers (conv_w1d)
                                  instead of the one that shares the transform through LDS (conv_w2d, the default)            */
@@ -140,7 +140,7 @@ typedef struct nd_step_profile {
     float ms_gemm;          /*   the other forms, and for batches above one Winograd chunk)                                  */
     float ms_xform_out;
     int form;               /* -1 pool; 0 direct implicit GEMM (conv_qp); 1 fused 1-D Winograd F(4,3) (conv_w1d); 2 F(2,3);  */
-                            /*   3 three-pass Winograd F(4x4,3x3): k_wino_input -> 36 GEMMs in one conv_qp launch -> k_wino_output */
+                            /*   3 three-pass Winograd F(6x6,3x3): k_wino_in2 -> 64 GEMMs in one conv_qp launch -> k_wino_out2      */
     int kind;               /* nd_layer_kind, -1 for pools                                                                  */
     double flops;           /* algorithmic FLOP for `batch` tiles (SURVEY.md 2a convention; 0 for pools)                    */
     double mfma_flops;      /* FLOP the matrix cores execute in that form (MFMA instructions x 4096)                        */
@@ -235,8 +235,8 @@ int nd_ssim_loss_grad(const float *x, const float *y, int n, int c, int h, int w
                       float *loss_acc, float *gx, int accumulate, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- Winograd forms of a 3x3 layer, fp32 inference (same math as nd_layer_forward on a CONV3 / CONVT3 layer, re-associated).
- * tile = 2 | 4: three-pass F(tile x tile, 3 x 3) (input transform, one launch of (tile+2)^2 GEMMs, output transform;
- *               Cin % 16 == 0; agrees with the direct kernel to ~1e-6 / ~1e-5 relative);
+ * tile = 2 | 4 | 6: three-pass F(tile x tile, 3 x 3) (input transform, one launch of (tile+2)^2 GEMMs, output transform;
+ *               Cin % 16 == 0; agrees with the direct kernel to ~1e-6 / ~1e-5 / ~2e-5 relative);
  * tile = 1 | 3: 1-D F(2,3) | F(4,3) along x inside the implicit-GEMM kernel, transform in registers (~1e-6 / ~5e-6);
  * tile = 5    : the same F(4,3) form with the input transform shared by the workgroup through LDS (conv_w2d). */
 size_t nd_winograd_packed_bytes(int tile, int cin, int cout);

@@ -24,7 +24,7 @@ class StepProfile(ctypes.Structure):
                 ("xform_bytes_in", c_double), ("xform_bytes_out", c_double)]
 
 
-FORM_NAMES = {-1: "pool", 0: "direct", 1: "w1d_f43", 2: "w1d_f23", 3: "wino3p_f4x4"}
+FORM_NAMES = {-1: "pool", 0: "direct", 1: "w1d_f43", 2: "w1d_f23", 3: "wino3p_f6x6"}
 
 
 class NindHipError(RuntimeError):

@@ -45,6 +45,15 @@ __device__ __forceinline__ void wino_g(int T, const float *g, float *u) {
         u[1] = 0.5f * (g[0] + g[1] + g[2]);
         u[2] = 0.5f * (g[0] - g[1] + g[2]);
         u[3] = g[2];
+    } else if (T == 6) {
+        u[0] = g[0];
+        u[1] = -2.f / 9.f * (g[0] + g[1] + g[2]);
+        u[2] = -2.f / 9.f * (g[0] - g[1] + g[2]);
+        u[3] = g[0] / 90.f + g[1] / 45.f + g[2] * 2.f / 45.f;
+        u[4] = g[0] / 90.f - g[1] / 45.f + g[2] * 2.f / 45.f;
+        u[5] = g[0] * 32.f / 45.f + g[1] * 16.f / 45.f + g[2] * 8.f / 45.f;
+        u[6] = g[0] * 32.f / 45.f - g[1] * 16.f / 45.f + g[2] * 8.f / 45.f;
+        u[7] = g[2];
     } else {
         u[0] = g[0] / 4.f;
         u[1] = -(g[0] + g[1] + g[2]) / 6.f;
@@ -106,13 +115,13 @@ __global__ void k_pack_wino_dev(int T, int kind, int cin, int cout, int KB, cons
                 float col[3];   // (G g)[i][kx] for kx = 0..2
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    float g[3], u[6];
+                    float g[3], u[8];
 #pragma unroll
                     for (int ky = 0; ky < 3; ++ky) g[ky] = tap3(kind, w, cin, cout, m, ci, ky, kx);
                     wino_g(T, g, u);
                     col[kx] = u[i];
                 }
-                float u[6];
+                float u[8];
                 wino_g(T, col, u);
                 v = u[j];
             }
@@ -147,7 +156,7 @@ int nd_pack_w1d_device(int T, int kind, int cin, int cout, const float *w, const
 }
 
 int nd_pack_wino_device(int T, int kind, int cin, int cout, const float *w, const float *bias, float *packed, hipStream_t s) {
-    if ((T != 2 && T != 4) || (kind != ND_CONV3 && kind != ND_CONVT3)) ND_FAIL(ND_EINVAL, "device Winograd packing: T = 2 | 4, 3x3 layers");
+    if ((T != 2 && T != 4 && T != 6) || (kind != ND_CONV3 && kind != ND_CONVT3)) ND_FAIL(ND_EINVAL, "device Winograd packing: T = 2 | 4 | 6, 3x3 layers");
     const int P = (T + 2) * (T + 2), KB = nd_kblocks(cin);
     const long gf = (long)nd_packed_floats(ND_CONV1, cin, cout, ND_F32);
     const long nwp = (long)nd_mtiles(ND_CONV1, cout) * KB * 256;

@@ -237,7 +237,7 @@ extern "C" int nd_utnet_profile_stack(int funit, int act, int dtype, int flags, 
         switch (form) {
             case FORM_W1D4: o.mfma_flops = 2.0 * 3 * 6 * cip * co * hout * cdiv(wout, 4) * B; break;
             case FORM_W1D2: o.mfma_flops = 2.0 * 3 * 4 * cip * co * hout * cdiv(wout, 2) * B; break;
-            case FORM_WINO3P: o.mfma_flops = 2.0 * 36 * cip * co * cdiv(hout, 4) * cdiv(wout, 4) * B; break;
+            case FORM_WINO3P: o.mfma_flops = 2.0 * (kWinoTile + 2) * (kWinoTile + 2) * cip * co * cdiv(hout, kWinoTile) * cdiv(wout, kWinoTile) * B; break;
             default:
                 o.mfma_flops = l.kind == ND_CONVT2S2 ? 2.0 * 4 * cip * co * hin * win * B
                                                      : 2.0 * nd_taps(l.kind) * cip * co * hout * wout * B;   // (zero-border MACs of a transposed layer included)
@@ -377,7 +377,7 @@ extern "C" int nd_layer_forward(int kind, int act, float slope, int dtype, const
 
 // Winograd form of a 3x3 layer (tile = 2 | 4): same interface as nd_layer_forward with a blob from nd_winograd_pack
 // (tile = 1 | 3: the 1-D F(2,3) | F(4,3) form fused into the implicit-GEMM kernel, conv_w1d.hip)
-static bool wino_tile_ok(int tile) { return tile >= 1 && tile <= 5; }   // 5: the F(4,3) form of tile 3 through conv_w2d
+static bool wino_tile_ok(int tile) { return tile >= 1 && tile <= 6; }   // 5: the F(4,3) form of tile 3 through conv_w2d; 6: three-pass F(6x6,3x3)
 extern "C" size_t nd_winograd_packed_bytes(int tile, int cin, int cout) {
     if (!wino_tile_ok(tile) || cin <= 0 || cout <= 0) return 0;
     if (tile == 5) tile = 3;

@@ -71,10 +71,11 @@ inline int lcin(const LayerSpec &l, int f) { return l.cin_mul ? l.cin_mul * f : 
 inline int lcout(const LayerSpec &l, int f) { return l.cout_mul ? l.cout_mul * f : 3; }
 
 // fp32 inference form of the 3x3 layers, chosen from measurements on the UtNet(64) shapes at 256 tiles per launch:
-//   Cin * Cout >= 128 * 256 : three-pass Winograd F(4x4, 3x3) (winograd.hip): 1.65x (128 -> 256) ... 2.6x (1024 -> 512) the direct kernel
+//   Cin * Cout >= 128 * 256 : three-pass Winograd F(6x6, 3x3) (winograd.hip; F(4x4) until late round 2): 1.65x (128 -> 256) ... 2.6x (1024 -> 512) the direct kernel
 //   below                   : 1-D Winograd F(4, 3) along x inside the implicit-GEMM kernel (conv_w1d.hip): 1.43 - 1.5x the direct
 //                             kernel; the three-pass form is HBM-bound on its transform passes there (64 -> 64: 0.87x, 128 -> 128: 1.4x)
-constexpr int kWinoTile = 4;
+constexpr int kWinoTile = 6;   // F(6x6,3x3): 64 MACs per 36 outputs and 1.78x |X| of transform traffic (F(4x4): 36 per 16, 2.25x); every
+                             // three-pass layer of UtNet(64) measured 1 - 27 % faster than with F(4x4) at cs = 264 (bottom.2, a 13x13 output, the least)
 constexpr int kW1dTile = 4;
 constexpr int kWinoChunk = 256;  // images per three-pass Winograd pass: bounds the V / M scratch (60 MB per 264-pixel tile for the
                                  // largest layer); G24 at 256 tiles per launch: 46.1 MP/s with 64, 47.4 with 128, 47.8 with 256

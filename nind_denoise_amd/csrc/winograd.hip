@@ -7,6 +7,8 @@
 //   3. k_wino_output  M[pos][Cout/4][tile] -> A^T m A + bias, activation -> destination buffer (HBM-bound)
 // It pays where channels are wide: pass 1 + 3 move ~2 (T+2)^2/T^2 x (|X| + |Y|) bytes, pass 2 saves 9 T^2/(T+2)^2 of the MFMAs.
 // ConvTranspose2d(3) is the same valid correlation on its zero-bordered input with flipped / transposed weights (as in pack.hip).
+#include <stdlib.h>
+
 #include <algorithm>
 #include <atomic>
 #include <thread>
@@ -61,6 +63,47 @@ template <> struct Wino<4> {
         o[3] = w[0] / 24 + w[1] / 12 + w[2] / 6;
         o[4] = w[0] / 24 - w[1] / 12 + w[2] / 6;
         o[5] = w[2];
+    }
+};
+
+// F(6,3): points 0, +-1, +-2, +-1/2, inf.  (8x8)/(6x6) = 1.78x the bytes of X in V (F(4,3): 2.25x) and 64 MACs per 36 outputs
+// (5.06x fewer than direct; F(4x4): 4x).  fp32 error on UtNet-scale data: ~2x that of F(4x4) (9e-6 against 4.6e-6 on O(1)
+// outputs of a 128-channel layer) -- the larger constants (21/4, 32) cost one more bit, not an order of magnitude.
+template <> struct Wino<6> {
+    static constexpr int A = 8;
+    template <typename V> __host__ __device__ static void bt(const V *d, V *o) {
+        o[0] = d[0] - d[6] + 5.25f * (d[4] - d[2]);
+        o[7] = d[7] - d[1] + 5.25f * (d[3] - d[5]);
+        V p = d[2] + d[6] - 4.25f * d[4], q = d[1] + d[5] - 4.25f * d[3];
+        o[1] = p + q;
+        o[2] = p - q;
+        p = 0.25f * d[2] - 1.25f * d[4] + d[6];
+        q = 0.5f * d[1] - 2.5f * d[3] + 2.f * d[5];
+        o[3] = p + q;
+        o[4] = p - q;
+        p = 4.f * d[2] - 5.f * d[4] + d[6];
+        q = 2.f * d[1] - 2.5f * d[3] + 0.5f * d[5];
+        o[5] = p + q;
+        o[6] = p - q;
+    }
+    template <typename V> __host__ __device__ static void at(const V *m, V *o) {
+        const V s1 = m[1] + m[2], d1 = m[1] - m[2], s2 = m[3] + m[4], d2 = m[3] - m[4], s3 = m[5] + m[6], d3 = m[5] - m[6];
+        o[0] = m[0] + s1 + s2 + s3;
+        o[1] = d1 + 2.f * d2 + 0.5f * d3;
+        o[2] = s1 + 4.f * s2 + 0.25f * s3;
+        o[3] = d1 + 8.f * d2 + 0.125f * d3;
+        o[4] = s1 + 16.f * s2 + 0.0625f * s3;
+        o[5] = d1 + 32.f * d2 + 0.03125f * d3 + m[7];
+    }
+    static void g(const double *w, double *o) {
+        o[0] = w[0];
+        o[1] = -2.0 / 9 * (w[0] + w[1] + w[2]);
+        o[2] = -2.0 / 9 * (w[0] - w[1] + w[2]);
+        o[3] = w[0] / 90 + w[1] / 45 + w[2] * 2 / 45;
+        o[4] = w[0] / 90 - w[1] / 45 + w[2] * 2 / 45;
+        o[5] = w[0] * 32 / 45 + w[1] * 16 / 45 + w[2] * 8 / 45;
+        o[6] = w[0] * 32 / 45 - w[1] * 16 / 45 + w[2] * 8 / 45;
+        o[7] = w[2];
     }
 };
 
@@ -186,6 +229,135 @@ __global__ __launch_bounds__(128) void k_wino_output(const f32x4 *__restrict__ m
     }
 }
 
+// The same two transforms with the tile shared by A threads through LDS (T = 6: a thread of the kernels above would hold 64 + 64
+// float4 = 512 VGPRs).  32 tiles per workgroup, 32 * A threads.
+//   input : pass 1 thread (tile, column j)  loads d[0..A)[j] (A lanes = 16 A contiguous bytes per tile row), column transform -> LDS
+//           pass 2 thread (row i, tile)     row transform of r[i][0..A), A position stores, each 512 B contiguous per half wave
+template <int T, int NTL>
+__global__ __launch_bounds__(NTL * (T + 2)) void k_wino_in2(const f32x4 *__restrict__ x, long xnp, int Hb, int Wb, int B, int TY, int TX,
+                                                            f32x4 *__restrict__ v, long vnp, long vbs) {
+    constexpr int A = Wino<T>::A, RS = A * A + 1;   // (+1: pass 2 reads a tile per lane, 16 (A*A+1) B apart: all banks)
+    __shared__ f32x4 sm[NTL * RS];
+    const long tiles = (long)B * TY * TX;
+    const long t0 = (long)blockIdx.x * NTL;
+    const int q = blockIdx.y;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    {
+        const int tl = threadIdx.x / A, j = threadIdx.x % A;
+        const long t = t0 + tl;
+        if (t < tiles) {
+            const int tx = (int)(t % TX), ty = (int)((t / TX) % TY), b = (int)(t / ((long)TX * TY));
+            const f32x4 *src = x + (long)q * xnp + ((long)b * Hb + T * ty) * Wb + T * tx + j;
+            f32x4 d[A], o[A];
+            const bool okj = T * tx + j < Wb;
+#pragma unroll
+            for (int i = 0; i < A; ++i) d[i] = (okj && T * ty + i < Hb) ? src[(long)i * Wb] : zero;
+            Wino<T>::bt(d, o);
+#pragma unroll
+            for (int i = 0; i < A; ++i) sm[tl * RS + i * A + j] = o[i];
+        }
+    }
+    __syncthreads();
+    {
+        const int i = threadIdx.x / NTL, tl = threadIdx.x % NTL;
+        const long t = t0 + tl;
+        if (t < tiles) {
+            f32x4 r[A], o[A];
+#pragma unroll
+            for (int j = 0; j < A; ++j) r[j] = sm[tl * RS + i * A + j];
+            Wino<T>::bt(r, o);
+            f32x4 *dst = v + (long)q * vnp + t;
+#pragma unroll
+            for (int j = 0; j < A; ++j) dst[(long)(i * A + j) * vbs] = o[j];
+        }
+    }
+}
+
+//   output: pass 1 thread (column j, tile)  loads m[0..A)[j] (tile-contiguous), column transform (A -> T) -> LDS
+//           pass 2 thread (row i < T, tile) row transform, bias, activation -> LDS row image [T][32 tiles x T pixels]
+//           pass 3 all threads              pixel-contiguous stores of the T rows (+ the 2x2 max pool of the tile rows, T even)
+template <int T>
+__global__ __launch_bounds__(32 * (T + 2)) void k_wino_out2(const f32x4 *__restrict__ m, long mnp, long mbs, int B, int TY, int TX, int Hv,
+                                                             int Wv, const float *__restrict__ bias, int act, float slope_imm,
+                                                             const float *__restrict__ slope_dev, f32x4 *__restrict__ out, long onp,
+                                                             int out_plane0, int Ho, int Wo, int opad, f32x4 *__restrict__ pool, long pnp,
+                                                             int Hp, int Wp, int ppad) {
+    constexpr int A = Wino<T>::A, NTL = 32, RS = T * A + 1, NTH = 32 * A;
+    __shared__ f32x4 sr[NTL * RS];
+    __shared__ f32x4 so[T][NTL * T];
+    const long tiles = (long)B * TY * TX;
+    const long t0 = (long)blockIdx.x * NTL;
+    const int q = blockIdx.y;
+    const f32x4 bv = *(const f32x4 *)(bias + 4 * q);
+    const float slope = act == ND_ACT_NONE ? 1.f : (slope_dev ? *slope_dev : slope_imm);
+    {
+        const int j = threadIdx.x / NTL, tl = threadIdx.x % NTL;
+        const long t = t0 + tl;
+        if (t < tiles) {
+            const f32x4 *src = m + (long)q * mnp + t;
+            f32x4 c[A], o[T];
+#pragma unroll
+            for (int i = 0; i < A; ++i) c[i] = src[(long)(i * A + j) * mbs];
+            Wino<T>::at(c, o);
+#pragma unroll
+            for (int i = 0; i < T; ++i) sr[tl * RS + i * A + j] = o[i];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < NTL * T) {
+        const int i = threadIdx.x / NTL, tl = threadIdx.x % NTL;
+        if (t0 + tl < tiles) {
+            f32x4 r[A], o[T];
+#pragma unroll
+            for (int j = 0; j < A; ++j) r[j] = sr[tl * RS + i * A + j];
+            Wino<T>::at(r, o);
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                f32x4 y = o[j] + bv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float u = y[e];
+                    switch (act) {
+                        case ND_ACT_ELU: y[e] = u > 0.f ? u : expm1f(u); break;
+                        case ND_ACT_HARDSWISH: y[e] = u * fminf(fmaxf(u + 3.f, 0.f), 6.f) / 6.f; break;
+                        default: y[e] = u > 0.f ? u : u * slope; break;   // PReLU; "none" is slope 1
+                    }
+                }
+                so[i][tl * T + j] = y;
+            }
+        }
+    }
+    __syncthreads();
+    f32x4 *dst = out + (long)(out_plane0 + q) * onp;
+    for (int idx = threadIdx.x; idx < T * NTL * T; idx += NTH) {
+        const int i = idx / (NTL * T), pp = idx - i * (NTL * T);
+        const long tt = t0 + pp / T;
+        if (tt >= tiles) continue;
+        const int tx = (int)(tt % TX), ty = (int)((tt / TX) % TY), b = (int)(tt / ((long)TX * TY));
+        const int xx = T * tx + pp % T, yy = T * ty + i;
+        if (xx < Wv && yy < Hv) dst[((long)b * Ho + yy + opad) * Wo + xx + opad] = so[i][pp];
+    }
+    if (pool) {   // fused MaxPool2d(2): tiles start on even pixels and T is even, so every 2x2 block lies inside one tile
+        f32x4 *pd = pool + (long)q * pnp;
+        for (int idx = threadIdx.x; idx < (T / 2) * NTL * (T / 2); idx += NTH) {
+            const int a = idx / (NTL * (T / 2)), pp = idx - a * (NTL * (T / 2));
+            const int tl = pp / (T / 2), c = pp % (T / 2);
+            const long tt = t0 + tl;
+            if (tt >= tiles) continue;
+            const int tx = (int)(tt % TX), ty = (int)((tt / TX) % TY), b = (int)(tt / ((long)TX * TY));
+            const int px = tx * (T / 2) + c, py = ty * (T / 2) + a;
+            if (2 * px + 1 < Wv && 2 * py + 1 < Hv) {
+                const f32x4 p00 = so[2 * a][tl * T + 2 * c], p01 = so[2 * a][tl * T + 2 * c + 1];
+                const f32x4 p10 = so[2 * a + 1][tl * T + 2 * c], p11 = so[2 * a + 1][tl * T + 2 * c + 1];
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaxf(p00[e], p01[e]), fmaxf(p10[e], p11[e]));
+                pd[((long)b * Hp + py + ppad) * Wp + px + ppad] = v;
+            }
+        }
+    }
+}
+
 int positions(int T) { return (T + 2) * (T + 2); }
 size_t gemm_floats(int cin, int cout) { return nd_packed_floats(ND_CONV1, cin, cout, ND_F32); }
 
@@ -221,7 +393,7 @@ size_t nd_wino_packed_floats(int T, int cin, int cout) {
 
 // w: torch layout of the layer (Conv2d: [cout][cin][3][3]; ConvTranspose2d: [cin][cout][3][3]); bias may be null
 int nd_wino_pack(int T, int kind, int cin, int cout, const float *w, const float *bias, float *packed) {
-    if (T != 2 && T != 4) ND_FAIL(ND_EINVAL, "winograd: tile must be 2 or 4");
+    if (T != 2 && T != 4 && T != 6) ND_FAIL(ND_EINVAL, "winograd: tile must be 2, 4 or 6");
     if (kind != ND_CONV3 && kind != ND_CONVT3) ND_FAIL(ND_EINVAL, "winograd: 3x3 layers only");
     const int A = T + 2, P = A * A;
     std::vector<float> u((size_t)P * cout * cin);
@@ -238,19 +410,19 @@ int nd_wino_pack(int T, int kind, int cin, int cout, const float *w, const float
     };
     parallel_for(cout, [&](int co) {
         for (int ci = 0; ci < cin; ++ci) {
-            double g[3][3], tmp[6][3], U[6][6];
+            double g[3][3], tmp[8][3], U[8][8];
             for (int ky = 0; ky < 3; ++ky)
                 for (int kx = 0; kx < 3; ++kx)
                     g[ky][kx] = kind == ND_CONV3 ? w[(((size_t)co * cin + ci) * 3 + ky) * 3 + kx]
                                                  : w[(((size_t)ci * cout + co) * 3 + (2 - ky)) * 3 + (2 - kx)];
             for (int kx = 0; kx < 3; ++kx) {   // columns: tmp[:, kx] = G g[:, kx]
-                double c[3] = {g[0][kx], g[1][kx], g[2][kx]}, o[6];
-                if (T == 2) Wino<2>::g(c, o); else Wino<4>::g(c, o);
+                double c[3] = {g[0][kx], g[1][kx], g[2][kx]}, o[8];
+                if (T == 2) Wino<2>::g(c, o); else if (T == 4) Wino<4>::g(c, o); else Wino<6>::g(c, o);
                 for (int i = 0; i < A; ++i) tmp[i][kx] = o[i];
             }
             for (int i = 0; i < A; ++i) {      // rows: U[i, :] = G tmp[i, :]
-                double o[6];
-                if (T == 2) Wino<2>::g(tmp[i], o); else Wino<4>::g(tmp[i], o);
+                double o[8];
+                if (T == 2) Wino<2>::g(tmp[i], o); else if (T == 4) Wino<4>::g(tmp[i], o); else Wino<6>::g(tmp[i], o);
                 for (int j = 0; j < A; ++j) U[i][j] = o[j];
             }
             for (int i = 0; i < A; ++i)
@@ -279,7 +451,7 @@ void nd_wino_xform_bytes(int T, const QpBuf &in, int cin, int cout, double *byte
 }
 
 int nd_launch_conv_wino(int T, const ConvDesc &d, void *scratch, size_t scratch_bytes, hipStream_t s, hipEvent_t *ev2) {
-    if (T != 2 && T != 4) ND_FAIL(ND_EINVAL, "winograd: tile must be 2 or 4");
+    if (T != 2 && T != 4 && T != 6) ND_FAIL(ND_EINVAL, "winograd: tile must be 2, 4 or 6");
     if ((d.kind != ND_CONV3 && d.kind != ND_CONVT3) || d.in.dt != ND_F32 || d.out.dt != ND_F32)
         ND_FAIL(ND_EINVAL, "winograd: fp32 3x3 layers only");
     if (d.cin % 16 || d.cout % 4) ND_FAIL(ND_EINVAL, "winograd: Cin must be a multiple of 16, Cout of 4 (got %d, %d)", d.cin, d.cout);
@@ -295,8 +467,21 @@ int nd_launch_conv_wino(int T, const ConvDesc &d, void *scratch, size_t scratch_
     const int in_planes = 2 * nd_kblocks(d.cin), out_planes = d.cout / 4;
     const f32x4 *x = (const f32x4 *)d.in.base + (long)d.in_plane0 * d.in.np();
     dim3 gi((unsigned)((g.tiles + 255) / 256), in_planes);
+    static const bool two_pass4 = getenv("ND_WINO_LDS4") != nullptr;   // A/B: the LDS-shared transform kernels for T = 4 too
+    // tiles per workgroup of the LDS-shared input transform: 16 (measured on UtNet(64) at cs = 264: 16 and 64 equal on every layer;
+    // 32 is 50 % slower on the 132 x 132 input of tconvs3.0 -- 3.45 against 2.27 ms -- and equal elsewhere); ND_WINO_NTL overrides
+    static const int ntl = getenv("ND_WINO_NTL") ? atoi(getenv("ND_WINO_NTL")) : 16;
+    dim3 gi2((unsigned)((g.tiles + ntl - 1) / ntl), in_planes);
     if (T == 2)
         hipLaunchKernelGGL(k_wino_input<2>, gi, dim3(256), 0, s, x, d.in.np(), d.in.Hb, d.in.Wb, d.in.B, g.TY, g.TX, v, g.vnp, g.vbs);
+    else if (T == 6 && ntl == 16)
+        hipLaunchKernelGGL((k_wino_in2<6, 16>), gi2, dim3(128), 0, s, x, d.in.np(), d.in.Hb, d.in.Wb, d.in.B, g.TY, g.TX, v, g.vnp, g.vbs);
+    else if (T == 6 && ntl == 64)
+        hipLaunchKernelGGL((k_wino_in2<6, 64>), gi2, dim3(512), 0, s, x, d.in.np(), d.in.Hb, d.in.Wb, d.in.B, g.TY, g.TX, v, g.vnp, g.vbs);
+    else if (T == 6)
+        hipLaunchKernelGGL((k_wino_in2<6, 32>), gi2, dim3(256), 0, s, x, d.in.np(), d.in.Hb, d.in.Wb, d.in.B, g.TY, g.TX, v, g.vnp, g.vbs);
+    else if (two_pass4)
+        hipLaunchKernelGGL((k_wino_in2<4, 32>), gi2, dim3(192), 0, s, x, d.in.np(), d.in.Hb, d.in.Wb, d.in.B, g.TY, g.TX, v, g.vnp, g.vbs);
     else
         hipLaunchKernelGGL(k_wino_input<4>, gi, dim3(256), 0, s, x, d.in.np(), d.in.Hb, d.in.Wb, d.in.B, g.TY, g.TX, v, g.vnp, g.vbs);
     ND_HIP(hipGetLastError());
@@ -351,7 +536,14 @@ int nd_launch_conv_wino(int T, const ConvDesc &d, void *scratch, size_t scratch_
         Wp = q.Wb;
         ppad = q.pad;
     }
-    if (T == 2)
+    dim3 go2((unsigned)((g.tiles + 31) / 32), out_planes);
+    if (T == 6)
+        hipLaunchKernelGGL(k_wino_out2<6>, go2, dim3(256), 0, s, (const f32x4 *)m, g.mnp, g.mbs, d.in.B, g.TY, g.TX, g.Hv, g.Wv, bias,
+                           d.act, d.slope, d.slope_dev, out, d.out.np(), d.out_plane0, d.out.Hb, d.out.Wb, d.out.pad, pool, pnp, Hp, Wp, ppad);
+    else if (T == 4 && two_pass4)
+        hipLaunchKernelGGL(k_wino_out2<4>, go2, dim3(192), 0, s, (const f32x4 *)m, g.mnp, g.mbs, d.in.B, g.TY, g.TX, g.Hv, g.Wv, bias,
+                           d.act, d.slope, d.slope_dev, out, d.out.np(), d.out_plane0, d.out.Hb, d.out.Wb, d.out.pad, pool, pnp, Hp, Wp, ppad);
+    else if (T == 2)
         hipLaunchKernelGGL(k_wino_output<2>, go, dim3(128), 0, s, (const f32x4 *)m, g.mnp, g.mbs, d.in.B, g.TY, g.TX, g.Hv, g.Wv, bias,
                            d.act, d.slope, d.slope_dev, out, d.out.np(), d.out_plane0, d.out.Hb, d.out.Wb, d.out.pad, pool, pnp, Hp, Wp, ppad);
     else

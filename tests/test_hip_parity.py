@@ -186,13 +186,13 @@ WINO_CASES = [
 
 
 @pytest.mark.parametrize("case", WINO_CASES, ids=lambda c: "-".join(str(v) for v in c))
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
 def test_layer_winograd(dev, case, tile):
     """Winograd F(t x t, 3 x 3) form of a 3x3 layer (csrc/winograd.hip: input transform, 16 / 36 batched GEMMs in one launch,
     output transform) against torch and against the direct kernel."""
     kind, B, cin, cout, H, W, act = case
     # tile 1 | 3 = the 1-D F(2,3) | F(4,3) form fused into the implicit-GEMM kernel; 2 | 4 = the three-pass F(2x2) | F(4x4) form;
-    # 5 = the F(4,3) form with the input transform shared by the workgroup through LDS (conv_w2d)
+    # 5 = the F(4,3) form with the input transform shared by the workgroup through LDS (conv_w2d); 6 = three-pass F(6x6)
     x = rnd((B, cin, H, W), 1)
     bound = 1.0 / np.sqrt(cin * 9)
     wshape = (cout, cin, 3, 3) if kind == "conv3" else (cin, cout, 3, 3)

@@ -85,7 +85,7 @@ def main():
             tot.setdefault(v, 0.0)
             tot[v] += ms.value
             if v == -1 and args.winograd and kind in ("conv3", "convT3") and args.dtype == "f32":
-                for tile in (3, 5, 4):   # 3 = 1-D F(4,3) in registers (conv_w1d), 5 = the same with the LDS-shared transform (conv_w2d), 4 = three-pass F(4x4,3x3)
+                for tile in (3, 5, 4, 6):   # 3 = 1-D F(4,3) in registers (conv_w1d), 5 = the same with the LDS-shared transform (conv_w2d), 4 | 6 = three-pass F(4x4,3x3) | F(6x6,3x3)
                     if tile % 2 == 0 and cin % 16:
                         continue
                     rc = lib.nd_winograd_bench(tile, k, args.batch, cin, cout, h, h, args.iters, ws.data_ptr(), ws.numel(),
