@@ -81,7 +81,9 @@ constexpr int kWinoChunk = 256;  // images per three-pass Winograd pass: bounds 
                                  // largest layer); G24 at 256 tiles per launch: 46.1 MP/s with 64, 47.4 with 128, 47.8 with 256
 inline bool wino_layer(const LayerSpec &l, int f, int dt) {
     return dt == ND_F32 && (l.kind == ND_CONV3 || l.kind == ND_CONVT3) && l.cin_mul * f >= 128 && l.cout_mul * f >= 128 &&
-           (long)l.cin_mul * f * l.cout_mul * f >= 128L * 256 && (l.cin_mul * f) % 16 == 0;
+           ((long)l.cin_mul * f * l.cout_mul * f >= 128L * 256 || l.kind == ND_CONVT3) && (l.cin_mul * f) % 16 == 0;
+    // (128 -> 128: the transposed layer tconvs3.2 is 0.47 ms faster in the three-pass form at 256 tiles of 264, the valid layer
+    //  convs2.2 -- which also writes its pooled tensor -- 0.16 ms slower)
 }
 
 // float offsets of every layer inside the packed blob
