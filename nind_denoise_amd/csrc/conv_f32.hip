@@ -12,7 +12,7 @@ static const Variant g_f32_extra[] = {
     ND_VARIANT(ND_F32, "f32", 2, 2, 1, 4, 9, 1, false, 3),  // M64  x N256, 4 waves, 3 stages
     ND_VARIANT(ND_F32, "f32", 2, 4, 4, 2, 1, 2, false, 3),  // 1 tap, M256 x N256 (64x128 per wave): the Winograd GEMMs (Cout % 256 == 0)
     ND_VARIANT(ND_F32, "f32", 2, 2, 2, 4, 1, 2, false, 3),  // 1 tap, M128 x N256
-    ND_VARIANT(ND_F32, "f32", 2, 4, 4, 2, 1, 4, false, 2),  // 1 tap, M256 x N256, 4 K blocks per step on 2 stages: 3-4 % faster from Cin = 512
+    ND_VARIANT(ND_F32, "f32", 2, 4, 4, 2, 1, 4, false, 2),  // 1 tap, M256 x N256, 4 K blocks per step on 2 stages: 3-6 % faster (any Cin % 32 == 0)
     ND_VARIANT(ND_F32, "f32", 2, 4, 2, 4, 1, 4, false, 2),  // 1 tap, M128 x N512, 4 K blocks per step: 2-4 % over M128 x N256
     ND_VARIANT(ND_F32, "f32", 2, 4, 4, 2, 1, 4, true, 2),   // up (2x2 s2), M256 x N256, 4 K blocks per step: 5-9 % over M128 x N256
 };
@@ -28,11 +28,13 @@ static const Variant &variant_at(int v) {
 
 
 int nd_conv_variant_count() { return g_nvariants; }
-// 1-tap fp32 variant for a Winograd GEMM of this shape (measured on the UtNet(64) layers at 64 tiles per pass), -1: automatic
+// 1-tap fp32 variant for a Winograd GEMM of this shape (measured on the UtNet(64) layers at 256 tiles per pass), -1: automatic
 int nd_conv_variant_gemm(int cin, int cout) {
     const int KB = nd_kblocks(cin), x = 3 * kGroup;
     if (KB % 2) return -1;
-    if (cout % 256 == 0) return (KB % 4 == 0 && cin >= 512) ? x + 4 : x + 2;
+    // (4 K blocks per step on two stages: re-measured with the 64-position GEMMs of F(6x6): 3 - 6 % faster than 2 blocks on three
+    //  stages from Cin = 128 up -- fewer barriers and epilogue-adjacent steps per tile)
+    if (cout % 256 == 0) return KB % 4 == 0 ? x + 4 : x + 2;
     if (cout % 128 == 0) return KB % 4 == 0 ? x + 5 : x + 3;
     return -1;
 }
