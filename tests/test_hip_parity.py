@@ -450,6 +450,23 @@ def test_utnet_f64_smallest_tile_and_many_tiles(dev):
     assert (yb[255] - yb[0]).abs().max().item() < 1e-5 and (yb[258] - yb[0]).abs().max().item() < 1e-5   # 255, 258 = tile 0 again
 
 
+def test_utnet_f64_winograd_tile_remainders(dev):
+    # production width at tile sizes whose three-pass layers leave every remainder of the 6 x 6 Winograd output tile (and partial
+    # 8-row strips of the fused 1-D form), square and non-square, odd batch sizes
+    from nind_denoise_amd.networks.UtNet import UtNet
+    from oracle import networks as onet
+    sd = synth.make_utnet_state_dict(funit=64, seed=7)
+    net = UtNet()
+    net.load_state_dict(sd)
+    net = net.eval().to(dev)
+    for (h, w), B in (((120, 120), 3), ((136, 136), 1), ((152, 152), 5), ((200, 200), 2), ((152, 104), 2), ((104, 216), 1)):
+        x = torch.rand(B, 3, h, w, generator=torch.Generator().manual_seed(h + w))
+        with torch.no_grad():
+            ref = onet.utnet_forward(sd, x)
+        err = assert_close(net(x.to(dev)), ref, f"f64 {h}x{w} batch {B}")
+        assert err <= 2e-6 * max(1.0, ref.abs().max().item()), (h, w, err)     # measured ~1e-7: the fp32 path, not just the 1e-3 bar
+
+
 def test_device_packed_weights_equal_host_packed(dev):
     # model load packs the fp32 blob (direct + both Winograd forms) in HBM; the host packer is the reference layout
     from nind_denoise_amd.networks.UtNet import UtNet
