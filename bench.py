@@ -142,7 +142,7 @@ def spawn_ranks(n):
 
 # ------------------------------------------------------------------------------------------------ roofline
 
-def conv_stack_profile(net, cs, batch, dev, reps=3):
+def conv_stack_profile(net, cs, batch, dev, reps=3, crop=0):
     """HIP-event timing of every launch of the conv stack for one batch (median over reps); the library reports which kernel
     family ran each layer and the FLOP its matrix cores executed (nd_step_profile, include/nind_hip.h)."""
     import numpy as np
@@ -155,7 +155,7 @@ def conv_stack_profile(net, cs, batch, dev, reps=3):
     runs = []
     for _ in range(reps + 1):
         _lib.check(lib.nd_utnet_profile_stack(net.funit, _lib.ACT[net.activation], _lib.DTYPE[net.compute_dtype], net.flags,
-                                              blob.data_ptr(), batch, cs, ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev),
+                                              blob.data_ptr(), batch, cs, crop, ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev),
                                               ctypes.cast(arr, ctypes.c_void_p), n))
         runs.append([(a.ms, a.ms_xform_in, a.ms_gemm, a.ms_xform_out) for a in arr])
     med = np.median(np.array(runs[1:]), axis=0)
@@ -449,7 +449,7 @@ def main():
         if not args.no_roofline:
             # (N > 1: rank 0 profiles the conv stack at the size of its own tile shard; the other ranks wait at the end)
             b = min(args.batch, hi - lo)
-            steps = conv_stack_profile(net, cs, b, dev)
+            steps = conv_stack_profile(net, cs, b, dev, crop=(cs - ucs) // 2)
             log("conv stack profile done")
             out["roofline"] = roofline_report(steps, args.dtype, cs, b, args.funit)
         if not args.no_host_leg and world == 1:

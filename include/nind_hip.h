@@ -59,8 +59,12 @@ typedef enum nd_flags {
                                  workgroups over the idle CUs: deterministic, but fp32 sums re-associate by <= 1e-5)        */
     ND_FLAG_DIRECT_CONV = 2,  /* direct convolution on every 3x3 layer (default on the fp32 path: Winograd F(6x6,3x3) from
                                  128 channels up, 1-D F(4,3) inside the implicit-GEMM kernel below; ~1e-5 re-association)   */
-    ND_FLAG_W1D_REGS = 4      /* A/B switch: the 1-D F(4,3) layers through the kernel that transforms in registers (conv_w1d)
+    ND_FLAG_W1D_REGS = 4,     /* A/B switch: the 1-D F(4,3) layers through the kernel that transforms in registers (conv_w1d)
                                  instead of the one that shares the transform through LDS (conv_w2d, the default)            */
+    ND_FLAG_FULL_TILES = 8    /* nd_utnet_denoise_tiles / nd_utnet_profile_stack: compute every layer on the whole tile, as
+                                 UtNet.forward does.  Default there: the last decoder levels compute only the pixels that the
+                                 useful crop [pad, cs - pad) of a tile can reach (denoise_image.py:249-258 discards the rest of
+                                 the network output before the canvas +=) -- same canvas, 19 % less work at cs 264 / ucs 200    */
 } nd_flags;
 
 int nd_version(void);
@@ -148,7 +152,9 @@ typedef struct nd_step_profile {
     double xform_bytes_in;  /* three-pass layers: algorithmic HBM bytes of the two transform passes                          */
     double xform_bytes_out;
 } nd_step_profile;
-int nd_utnet_profile_stack(int funit, int act, int dtype, int flags, const void *packed_dev, int batch, int cs,
+/* crop: margin of the useful tile centre the caller will keep ((cs - ucs) / 2 of the denoise loop; 0: the whole output, as
+ * nd_utnet_forward computes it) -- the stack then runs exactly as inside nd_utnet_denoise_tiles with the same flags */
+int nd_utnet_profile_stack(int funit, int act, int dtype, int flags, const void *packed_dev, int batch, int cs, int crop,
                            void *workspace, size_t workspace_bytes, void *stream, nd_step_profile *steps, int max_steps);
 const char *nd_utnet_step_name(int i);
 

@@ -14,7 +14,7 @@ DTYPE = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "f16": 2, 
 ACT = {"none": 0, "PReLU": 1, "ELU": 2, "Hardswish": 3}
 KIND = {"conv3": 0, "convT3": 1, "convT2s2": 2, "conv1": 3, "conv2s2": 4}
 # nd_flags (include/nind_hip.h): per-call arithmetic switches
-FLAG_NO_SPLITK, FLAG_DIRECT_CONV, FLAG_W1D_REGS = 1, 2, 4
+FLAG_NO_SPLITK, FLAG_DIRECT_CONV, FLAG_W1D_REGS, FLAG_FULL_TILES = 1, 2, 4, 8
 
 
 class StepProfile(ctypes.Structure):
@@ -64,7 +64,7 @@ _SIGNATURES = {
     "nd_unet_workspace_init": (c_int, [c_void_p, c_size_t] + [c_int] * 4 + [c_void_p]),
     "nd_unet_forward": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "nd_utnet_flops": (c_double, [c_int, c_int]),
-    "nd_utnet_profile_stack": (c_int, [c_int] * 4 + [c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_int]),
+    "nd_utnet_profile_stack": (c_int, [c_int] * 4 + [c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_int]),
     "nd_utnet_step_name": (c_char_p, [c_int]),
     "nd_layer_packed_bytes": (c_size_t, [c_int] * 4),
     "nd_layer_pack": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_size_t]),

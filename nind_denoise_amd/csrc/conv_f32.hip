@@ -48,10 +48,15 @@ static void valid_grid(int taps, const QpBuf &in, int *Hv, int *Wv, int *stride)
     *Hv = taps == 9 ? in.Hb - 2 : (in.Hb - 2 * in.pad) / *stride;
     *Wv = taps == 9 ? in.Wb - 2 : (in.Wb - 2 * in.pad) / *stride;
 }
-static int tile_span(const Variant &V, const QpBuf &in, bool cross) {
+// (Hv_o x Wv_o > 0: the valid grid is a region of the buffer's -- same strides, more row / image gaps per tile)
+static int tile_span(const Variant &V, const QpBuf &in, bool cross, int Hv_o = 0, int Wv_o = 0) {
     const int taps = V.taps;
     int Hv, Wv, s;
     valid_grid(taps, in, &Hv, &Wv, &s);
+    if (Hv_o > 0) {
+        Hv = Hv_o;
+        Wv = Wv_o;
+    }
     const int n = V.nblk;
     // consecutive valid pixels are s input pixels apart; every row end adds s*(Wb - Wv), every image end the rest of the image
     int span = s * n + s * (in.Wb - Wv) * ((n - 1) / Wv + 1);
@@ -65,13 +70,13 @@ static size_t lds_for(const Variant &V, int G) {
     return (size_t)V.nstage * ((size_t)(V.mblk / 32) * V.kbc * V.taps * 1024 + (size_t)2 * V.kbc * G * 1024);
 }
 // tiles may cross images when that still fits the LDS (small images: no padding of every image to a tile multiple)
-static size_t variant_lds(const Variant &V, const QpBuf &in, bool *cross_out = nullptr, int *G_out = nullptr) {
+static size_t variant_lds(const Variant &V, const QpBuf &in, bool *cross_out = nullptr, int *G_out = nullptr, int Hv_o = 0, int Wv_o = 0) {
     const size_t kMax = 160 * 1024;
-    int G = (tile_span(V, in, true) + 63) / 64;
+    int G = (tile_span(V, in, true, Hv_o, Wv_o) + 63) / 64;
     bool cross = true;
     if (lds_for(V, G) > kMax) {
         cross = false;
-        G = (tile_span(V, in, false) + 63) / 64;
+        G = (tile_span(V, in, false, Hv_o, Wv_o) + 63) / 64;
     }
     if (cross_out) *cross_out = cross;
     if (G_out) *G_out = G;
@@ -193,6 +198,8 @@ int nd_launch_split_finish(const ConvParams &p, int n_split_tiles, int mblk, int
 }
 
 static int pick_variant(const ConvDesc &d, int M) {
+    // (a region of interest shortens the rows of valid pixels: more row gaps per tile, a longer LDS halo image)
+    const int Hr = d.roi_rows > 0 ? d.roi_rows : 0, Wr = d.roi_rows > 0 ? d.roi_cols : 0;
     const int taps = nd_taps(d.kind);
     const bool up = d.kind == ND_CONVT2S2;
     const int dt = d.in.dt;
@@ -215,7 +222,7 @@ static int pick_variant(const ConvDesc &d, int M) {
                 const Variant &V = variant_at(g0 + c.v);
                 if (c.v == 14 && (M < 128 || dt == ND_F32)) continue;
                 bool cross = true;
-                if (variant_lds(V, d.in, &cross) > kMaxLds) continue;
+                if (variant_lds(V, d.in, &cross, nullptr, Hr, Wr) > kMaxLds) continue;
                 const long pv = (long)Hv * Wv;
                 const long tn = cross ? ((long)d.in.B * pv + V.nblk - 1) / V.nblk : ((pv + V.nblk - 1) / V.nblk) * d.in.B;
                 const long tiles = tn * ((M + V.mblk - 1) / V.mblk);
@@ -230,13 +237,26 @@ static int pick_variant(const ConvDesc &d, int M) {
         }
         const int order[] = {M <= 32 ? 3 : 0, 0, 1, 2};
         for (int v : order)
-            if (variant_lds(variant_at(g0 + v), d.in) <= kMaxLds) return g0 + v;
+            if (variant_lds(variant_at(g0 + v), d.in, nullptr, nullptr, Hr, Wr) <= kMaxLds) return g0 + v;
         return g0 + 2;
     }
-    if (taps == 4) return g0 + (variant_lds(variant_at(g0 + 12), d.in) <= kMaxLds ? 12 : 13);
+    if (taps == 4) return g0 + (variant_lds(variant_at(g0 + 12), d.in, nullptr, nullptr, Hr, Wr) <= kMaxLds ? 12 : 13);
     if (KB % 2) return g0 + (up ? 7 : 5);
-    if (up && dt == ND_F32 && M % 256 == 0 && KB % 4 == 0) return 3 * kGroup + 6;
-    if (up) return g0 + (M >= 128 ? (KB % 4 == 0 ? 10 : 8) : (KB % 4 == 0 ? 9 : 6));
+    if (up) {
+        // preferred shape first, then the ones with shorter K chunks / more stages whose stage images still fit the LDS
+        int cand[8], n = 0;
+        if (dt == ND_F32 && M % 256 == 0 && KB % 4 == 0) cand[n++] = 3 * kGroup + 6;
+        if (M >= 128) {
+            if (KB % 4 == 0) cand[n++] = g0 + 10;
+            if (KB % 2 == 0) cand[n++] = g0 + 8;
+        }
+        if (KB % 4 == 0) cand[n++] = g0 + 9;
+        if (KB % 2 == 0) cand[n++] = g0 + 6;
+        cand[n++] = g0 + 7;
+        for (int i = 0; i < n; ++i)
+            if (variant_lds(variant_at(cand[i]), d.in, nullptr, nullptr, Hr, Wr) <= kMaxLds) return cand[i];
+        return cand[n - 1];
+    }
     return g0 + 4;
 }
 
@@ -271,16 +291,25 @@ int nd_launch_conv(const ConvDesc &d, hipStream_t stream) {
     p.in = (const f32x4 *)d.in.base + (long)d.in_plane0 * d.in.np();
     p.wpk = d.wpk;
     p.bias = d.bias;
-    p.out = (f32x4 *)d.out.base;
+    p.out = (f32x4 *)d.out.base + (d.roi_rows > 0 ? (long)((up ? 2 : 1) * d.roi_r0) * d.out.Wb + (up ? 2 : 1) * d.roi_c0 : 0);
     p.in_plane = d.in.np();
     p.out_plane = d.out.np();
     p.nimg = d.in.B;
     p.P = d.in.Hb * d.in.Wb;
     p.Wb = d.in.Wb;
     valid_grid(taps, d.in, &p.Hv, &p.Wv, &p.stride);
+    const bool roi = d.roi_rows > 0;
+    if (roi) {
+        // region of the valid grid (of the INPUT grid for a 2x2 stride-2 transpose): same launch, shifted first pixel, smaller valid
+        // extents (the kernel takes the row / image strides from the buffer and the extents from Hv / Wv)
+        if (taps == 4 || d.roi_r0 < 0 || d.roi_c0 < 0 || d.roi_cols < 1 || d.roi_r0 + d.roi_rows > p.Hv || d.roi_c0 + d.roi_cols > p.Wv || d.nbatch > 1 || d.pre)
+            ND_FAIL(ND_EINVAL, "conv: region [%d,+%d) x [%d,+%d) outside the %d x %d grid (or a batched / training launch)", d.roi_r0, d.roi_rows, d.roi_c0, d.roi_cols, p.Hv, p.Wv);
+        p.Hv = d.roi_rows;
+        p.Wv = d.roi_cols;
+    }
     p.PV = p.Hv * p.Wv;
     if (taps == 4 && ((d.in.Hb | d.in.Wb) & 1)) ND_FAIL(ND_EINVAL, "conv: the stride-2 layer reads even-sized buffers only");
-    p.ioff = taps == 9 ? 0 : d.in.pad * d.in.Wb + d.in.pad;
+    p.ioff = (taps == 9 ? 0 : d.in.pad * d.in.Wb + d.in.pad) + (roi ? d.roi_r0 * d.in.Wb + d.roi_c0 : 0);
     p.pre = (f32x4 *)d.pre;
     p.pre_plane = d.pre_plane;
     if (d.pre && (dt != ND_F32 || up)) ND_FAIL(ND_EINVAL, "conv: the pre-activation copy exists for fp32 non-upsampling layers only");
@@ -298,15 +327,15 @@ int nd_launch_conv(const ConvDesc &d, hipStream_t stream) {
     // destination geometry must hold the result
     const int oh = up ? 2 * p.Hv : p.Hv, ow = up ? 2 * p.Wv : p.Wv;
     // (a 2x2 stride-2 result may be smaller than its destination: UNet's F.pad fix-up for odd sizes, ThirdPartyNets.py:110-118)
-    const bool fits = up ? (d.out.Hb >= oh + 2 * d.out.pad && d.out.Wb >= ow + 2 * d.out.pad)
-                         : (d.out.Hb == oh + 2 * d.out.pad && d.out.Wb == ow + 2 * d.out.pad);
+    const bool fits = (up || roi) ? (d.out.Hb >= oh + 2 * d.out.pad && d.out.Wb >= ow + 2 * d.out.pad)
+                                  : (d.out.Hb == oh + 2 * d.out.pad && d.out.Wb == ow + 2 * d.out.pad);
     if (!fits || d.out.B != d.in.B)
         ND_FAIL(ND_EINVAL, "conv: destination %dx%dx%d(pad %d) does not fit result %dx%dx%d", d.out.B, d.out.Hb, d.out.Wb,
                 d.out.pad, d.in.B, oh, ow);
     if (d.out_plane0 + d.cout / nd_cpp(dt) > d.out.planes) ND_FAIL(ND_EINVAL, "conv: destination planes overflow");
 
     bool cross = true;
-    const size_t lds = variant_lds(V, d.in, &cross, &p.G);
+    const size_t lds = variant_lds(V, d.in, &cross, &p.G, roi ? p.Hv : 0, roi ? p.Wv : 0);
     if (lds > kMaxLds) ND_FAIL(ND_EINVAL, "conv: %zu B of LDS needed (row width %d too large for variant %s)", lds, p.Wb, V.name);
     int dev = 0;
     ND_HIP(hipGetDevice(&dev));

@@ -530,12 +530,18 @@ bool nd_w2d_ok(const QpBuf &in) { return in.dt == ND_F32 && in.Hb >= 3 && in.Wb 
 int nd_launch_conv_w2d(const ConvDesc &d, hipStream_t stream) {
     if ((d.kind != ND_CONV3 && d.kind != ND_CONVT3) || d.in.dt != ND_F32 || d.out.dt != ND_F32) ND_FAIL(ND_EINVAL, "w2d: fp32 3x3 layers only");
     const int KB = nd_kblocks(d.cin);
-    const int Hv = d.in.Hb - 2, Wpx = d.in.Wb - 2, Wg = (Wpx + 3) / 4, NB = (Hv + kR - 1) / kR;
-    if (Hv < 1 || Wpx < 1) ND_FAIL(ND_EINVAL, "w2d: input smaller than the kernel");
+    const int Hfull = d.in.Hb - 2, Wfull = d.in.Wb - 2;
+    if (Hfull < 1 || Wfull < 1) ND_FAIL(ND_EINVAL, "w2d: input smaller than the kernel");
+    const bool roi = d.roi_rows > 0;
+    if (roi && (d.roi_r0 < 0 || d.roi_c0 < 0 || d.roi_cols < 1 || d.roi_r0 + d.roi_rows > Hfull || d.roi_c0 + d.roi_cols > Wfull || d.pool))
+        ND_FAIL(ND_EINVAL, "w2d: region [%d,+%d) x [%d,+%d) outside the %d x %d output (or a pooled layer)", d.roi_r0, d.roi_rows, d.roi_c0, d.roi_cols, Hfull, Wfull);
+    // (a region is the same launch on shifted base pointers: the kernel knows row / image strides and valid extents separately)
+    const int Hv = roi ? d.roi_rows : Hfull, Wpx = roi ? d.roi_cols : Wfull, Wg = (Wpx + 3) / 4, NB = (Hv + kR - 1) / kR;
+    const long roi_in = roi ? (long)d.roi_r0 * d.in.Wb + d.roi_c0 : 0, roi_out = roi ? (long)d.roi_r0 * d.out.Wb + d.roi_c0 : 0;
     if (d.pre) ND_FAIL(ND_EINVAL, "w2d: inference only (no pre-activation copy; the training step uses conv_w1d)");
     if (d.cout % 4) ND_FAIL(ND_EINVAL, "w2d: cout must be a multiple of 4");
     if (d.in.planes < d.in_plane0 + 2 * KB) ND_FAIL(ND_EINVAL, "w2d: input buffer has %d planes, needs %d", d.in.planes, d.in_plane0 + 2 * KB);
-    if (d.out.Hb != Hv + 2 * d.out.pad || d.out.Wb != Wpx + 2 * d.out.pad || d.out.B != d.in.B) ND_FAIL(ND_EINVAL, "w2d: destination does not fit the result");
+    if (d.out.Hb != Hfull + 2 * d.out.pad || d.out.Wb != Wfull + 2 * d.out.pad || d.out.B != d.in.B) ND_FAIL(ND_EINVAL, "w2d: destination does not fit the result");
     if (d.out_plane0 + d.cout / 4 > d.out.planes) ND_FAIL(ND_EINVAL, "w2d: destination planes overflow");
     // a lane's float4 index inside a K block's two-plane window is 32 bits; strips of the last band / group read up to 9 rows + 5
     // pixels past the last valid pixel (the buffers carry that slack)
@@ -575,10 +581,10 @@ int nd_launch_conv_w2d(const ConvDesc &d, hipStream_t stream) {
     }
 
     ConvParams p = {};
-    p.in = (const f32x4 *)d.in.base + (long)d.in_plane0 * d.in.np();
+    p.in = (const f32x4 *)d.in.base + (long)d.in_plane0 * d.in.np() + roi_in;
     p.wpk = d.wpk;
     p.bias = d.bias;
-    p.out = (f32x4 *)d.out.base;
+    p.out = (f32x4 *)d.out.base + roi_out;
     p.in_plane = d.in.np();
     p.out_plane = d.out.np();
     p.nimg = d.in.B;

@@ -72,6 +72,11 @@ struct ConvDesc {
     // fused MaxPool2d(2) (fp32 inference, conv_w2d.hip / winograd.hip): the layer also writes max over 2x2 blocks of its activated
     // output into planes [0, cout/4) of `pool` (UtNet.py:99-105: every pooled tensor is a conv output that is also a skip)
     const QpBuf *pool = nullptr;
+    // region of interest (rows == 0: the whole layer).  3x3 layers (conv_w2d, three-pass F(6x6)): rectangle [r0, r0 + rows) x
+    // [c0, c0 + cols) of the valid OUTPUT grid -- only these outputs are computed and stored, from input rows [r0, r0 + rows + 2);
+    // 2x2 stride-2 transpose: rectangle of the INPUT grid (each input pixel makes its 2x2 outputs).  Used by the fused denoise
+    // loop: the last decoder levels only compute what the useful crop of a tile can reach (utnet_net.h: plan_rois)
+    int roi_r0 = 0, roi_c0 = 0, roi_rows = 0, roi_cols = 0;
 };
 // scratch that lets every layer split its partial round: 512 work items of 64 x 1024 accumulators
 static const size_t kSplitScratchBytes = (size_t)512 * 64 * 1024 * 4;

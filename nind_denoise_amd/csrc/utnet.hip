@@ -135,7 +135,7 @@ static int forward_common(int funit, int act, int dtype, const void *packed, int
 }
 
 static int check_flags(int flags) {
-    if (flags & ~(ND_FLAG_NO_SPLITK | ND_FLAG_DIRECT_CONV | ND_FLAG_W1D_REGS)) ND_FAIL(ND_EINVAL, "unknown flag bits 0x%x", flags);
+    if (flags & ~(ND_FLAG_NO_SPLITK | ND_FLAG_DIRECT_CONV | ND_FLAG_W1D_REGS | ND_FLAG_FULL_TILES)) ND_FAIL(ND_EINVAL, "unknown flag bits 0x%x", flags);
     return ND_OK;
 }
 extern "C" int nd_utnet_forward_hw(int funit, int act, int dtype, int flags, const void *packed, const float *x, float *y,
@@ -170,8 +170,14 @@ extern "C" int nd_utnet_denoise_tiles(int funit, int act, int dtype, int flags, 
     hipStream_t s = (hipStream_t)stream;
     const float *blob = (const float *)packed;
     ND_TRY(nd_launch_gather_pack(img, width, height, cs, ucs, ol, tile_begin, tile_count, pl.buf[X0], s));
-    ND_TRY(run_stack(funit, act, dtype, blob, pl, s, flags));
     const BlobLayout bl = blob_layout(funit, dtype);
+    // only the useful centre [pad, cs - pad) of a tile reaches the canvas (k_final1x1_stitch reads nothing else): the last decoder
+    // levels compute just what that centre depends on
+    Roi rois[kNumSteps];
+    const Roi *use = nullptr;
+    const int crop = (cs - ucs) / 2;
+    if (!(flags & ND_FLAG_FULL_TILES) && plan_rois(pl, crop, crop, rois) && rois_supported(funit, dtype, flags, pl, bl, rois)) use = rois;
+    ND_TRY(run_stack(funit, act, dtype, blob, pl, s, flags, nullptr, nullptr, nullptr, nullptr, nullptr, use));
     const float *fw = blob + bl.off[kNumLayers - 1];
     ND_TRY(nd_launch_final1x1_stitch(pl.buf[T4B], funit, fw, fw + 3 * funit, 2, canvas, width, height, cs, ucs, ol,
                                      tile_begin, tile_count, s));
@@ -182,8 +188,8 @@ extern "C" int nd_utnet_denoise_tiles(int funit, int act, int dtype, int flags, 
 // `stream` (and around the GEMM launch of a three-pass Winograd layer).  Synchronises the stream.  26 entries, forward order:
 // 22 MFMA conv layers and 4 pools.  FLOP conventions: `flops` = algorithmic (torch FlopCounterMode, no
 // padding-zero MACs); `mfma_flops` = what the matrix cores execute in the form the layer ran in (MFMAs issued x 4096).
-extern "C" int nd_utnet_profile_stack(int funit, int act, int dtype, int flags, const void *packed, int batch, int cs, void *ws,
-                                      size_t ws_bytes, void *stream, nd_step_profile *steps, int max_steps) {
+extern "C" int nd_utnet_profile_stack(int funit, int act, int dtype, int flags, const void *packed, int batch, int cs, int crop,
+                                      void *ws, size_t ws_bytes, void *stream, nd_step_profile *steps, int max_steps) {
     ND_TRY(check_flags(flags));
     Plan pl;
     ND_TRY(forward_common(funit, act, dtype, packed, batch, batch, cs, cs, ws, ws_bytes, &pl));
@@ -192,7 +198,12 @@ extern "C" int nd_utnet_profile_stack(int funit, int act, int dtype, int flags, 
     hipEvent_t ev[kNumSteps + 1], evx[2 * kNumSteps];
     for (auto &e : ev) ND_HIP(hipEventCreate(&e));
     for (auto &e : evx) ND_HIP(hipEventCreate(&e));
-    int rc = run_stack(funit, act, dtype, (const float *)packed, pl, s, flags, ev, nullptr, nullptr, nullptr, evx);
+    const BlobLayout bl = blob_layout(funit, dtype);
+    Roi rois[kNumSteps];
+    const Roi *use = nullptr;
+    if (crop < 0 || 2 * crop >= cs) ND_FAIL(ND_EINVAL, "nd_utnet_profile_stack: crop %d", crop);
+    if (!(flags & ND_FLAG_FULL_TILES) && plan_rois(pl, crop, crop, rois) && rois_supported(funit, dtype, flags, pl, bl, rois)) use = rois;
+    int rc = run_stack(funit, act, dtype, (const float *)packed, pl, s, flags, ev, nullptr, nullptr, nullptr, evx, use);
     if (rc == ND_OK) {
         hipError_t e = hipStreamSynchronize(s);
         if (e != hipSuccess) {
@@ -200,7 +211,6 @@ extern "C" int nd_utnet_profile_stack(int funit, int act, int dtype, int flags, 
             rc = ND_EHIP;
         }
     }
-    const BlobLayout bl = blob_layout(funit, dtype);
     for (int i = 0; i < kNumSteps && rc == ND_OK; ++i) {
         nd_step_profile &o = steps[i];
         memset(&o, 0, sizeof(o));
@@ -215,7 +225,12 @@ extern "C" int nd_utnet_profile_stack(int funit, int act, int dtype, int flags, 
         o.kind = st.layer >= 0 ? kLayers[st.layer].kind : -1;
         const QpBuf &in = pl.buf[st.src], &out = pl.buf[st.dst];
         const double B = batch, esz = 16.0 / nd_cpp(dtype);      // bytes per stored channel value
-        const double hin = in.Hb - 2 * in.pad, win = in.Wb - 2 * in.pad;
+        double hin = in.Hb - 2 * in.pad, win = in.Wb - 2 * in.pad;
+        if (use && use[i].rows > 0) {   // the layer ran on a region: count what it computed
+            const bool t3 = kLayers[st.layer].kind == ND_CONVT3;
+            hin = use[i].rows - (t3 ? 2 : 0);   // (a transposed 3x3 layer's region is on its output grid = input + 2)
+            win = use[i].cols - (t3 ? 2 : 0);
+        }
         if (st.layer < 0) {
             const double c = st.dst_plane0_mul * funit;
             o.bytes = B * c * esz * (hin * win + (hin / 2) * (win / 2));
@@ -252,6 +267,10 @@ extern "C" int nd_utnet_profile_stack(int funit, int act, int dtype, int flags, 
                 o.ms_xform_out = c;
             }
             QpBuf v = in;
+            if (use && use[i].rows > 0) {   // the passes ran on a view of rows + 2 x cols + 2 bordered input pixels
+                v.Hb = use[i].rows + 2;
+                v.Wb = use[i].cols + 2;
+            }
             nd_wino_xform_bytes(kWinoTile, v, (int)ci, (int)co, &o.xform_bytes_in, &o.xform_bytes_out);
         }
     }

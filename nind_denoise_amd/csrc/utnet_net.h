@@ -262,6 +262,88 @@ inline Form step_form(const Step &st, int f, int dt, int flags, const Plan &pl, 
     return bl.woff[st.layer] ? FORM_WINO3P : FORM_DIRECT;
 }
 
+// Regions of interest of the decoder layers when only the centre [crop_h, H - crop_h) x [crop_w, W - crop_w) of the network
+// output is used -- the fused denoise loop (denoise_image.py:249-258 crops every tile to its useful part before it is added to
+// the canvas: pixels outside [pad, cs - pad) never reach it).  Walking the stack backwards from the final 1x1: a transposed 3x3
+// layer needs input rows [lo - 2, hi) for output rows [lo, hi), a 2x2 stride-2 transpose input rows [lo / 2, (hi + 1) / 2).  With
+// cs = 264 / ucs = 200 the last decoder level computes 204^2 of its 266^2 pixels, the level below 104^2 of 130^2; from the
+// third level down everything is needed.  The encoder always runs whole (its pooled outputs feed every level).
+struct Roi { int r0, c0, rows, cols; };
+inline bool plan_rois(const Plan &pl, int crop_h, int crop_w, Roi *roi) {
+    for (int i = 0; i < kNumSteps; ++i) roi[i] = Roi{0, 0, 0, 0};
+    if (crop_h <= 0 && crop_w <= 0) return false;
+    bool any = false;
+    int lo[2][NBUF], hi[2][NBUF];
+    for (int dim = 0; dim < 2; ++dim) {
+        for (int b = 0; b < NBUF; ++b) {
+            lo[dim][b] = 1 << 30;
+            hi[dim][b] = -1;
+        }
+        const QpBuf &last = pl.buf[T4B];
+        const int size = (dim ? last.Wb : last.Hb) - 2 * last.pad, crop = dim ? crop_w : crop_h;
+        lo[dim][T4B] = crop + 2;          // final 1x1 + ZeroPad2d(-2): output pixel y is T4B pixel y + 2
+        hi[dim][T4B] = size - 2 - crop;
+        for (int i = kNumSteps - 1; i >= 0; --i) {
+            const Step &st = kSteps[i];
+            if (st.layer < 0) continue;
+            const int kind = kLayers[st.layer].kind;
+            if (kind != ND_CONVT3 && kind != ND_CONVT2S2) continue;
+            if (hi[dim][st.dst] < 0) continue;   // nobody restricted this output
+            const QpBuf &src = pl.buf[st.src];
+            const int si = (dim ? src.Wb : src.Hb) - 2 * src.pad;
+            int a = lo[dim][st.dst], b = hi[dim][st.dst];
+            if (kind == ND_CONVT3) {
+                a = a - 2 < 0 ? 0 : a - 2;
+                b = b > si ? si : b;
+            } else {
+                a = a >> 1;
+                b = (b + 1) >> 1;
+                b = b > si ? si : b;
+            }
+            if (a < lo[dim][st.src]) lo[dim][st.src] = a;
+            if (b > hi[dim][st.src]) hi[dim][st.src] = b;
+        }
+    }
+    for (int i = 0; i < kNumSteps; ++i) {
+        const Step &st = kSteps[i];
+        if (st.layer < 0) continue;
+        const int kind = kLayers[st.layer].kind;
+        if (kind != ND_CONVT3 && kind != ND_CONVT2S2) continue;
+        // the region lives on the layer's output grid (3x3) or input grid (2x2 stride-2)
+        const Buf b = kind == ND_CONVT3 ? st.dst : st.src;
+        const QpBuf &q = pl.buf[b];
+        const int H = q.Hb - 2 * q.pad, W = q.Wb - 2 * q.pad;
+        int r0 = 0, r1 = H, c0 = 0, c1 = W;
+        if (kind == ND_CONVT3) {
+            if (hi[0][b] >= 0) { r0 = lo[0][b]; r1 = hi[0][b]; }
+            if (hi[1][b] >= 0) { c0 = lo[1][b]; c1 = hi[1][b]; }
+        } else {
+            if (hi[0][st.dst] >= 0) { r0 = lo[0][st.dst] >> 1; r1 = (hi[0][st.dst] + 1) >> 1; }
+            if (hi[1][st.dst] >= 0) { c0 = lo[1][st.dst] >> 1; c1 = (hi[1][st.dst] + 1) >> 1; }
+        }
+        r0 = r0 < 0 ? 0 : r0; c0 = c0 < 0 ? 0 : c0;
+        r1 = r1 > H ? H : r1; c1 = c1 > W ? W : c1;
+        if (r0 == 0 && c0 == 0 && r1 == H && c1 == W) continue;
+        if (r1 <= r0 || c1 <= c0) continue;
+        roi[i] = Roi{r0, c0, r1 - r0, c1 - c0};
+        any = true;
+    }
+    return any;
+}
+
+// every restricted layer must run in a kernel that takes a region (conv_qp, conv_w2d, three-pass F(6x6)): one that does not would
+// compute its whole output from a producer that only wrote its region
+inline bool rois_supported(int f, int dt, int flags, const Plan &pl, const BlobLayout &bl, const Roi *rois) {
+    for (int i = 0; i < kNumSteps; ++i) {
+        if (rois[i].rows <= 0) continue;
+        const Form form = step_form(kSteps[i], f, dt, flags, pl, bl, false, nullptr);
+        if (form == FORM_DIRECT || form == FORM_WINO3P) continue;
+        if (form == FORM_W1D4 && !(flags & ND_FLAG_W1D_REGS)) continue;
+        return false;
+    }
+    return true;
+}
+
 // ev (optional): kNumSteps+1 events, ev[i] recorded before step i, ev[kNumSteps] after the last one;
 // ev_x (optional, with ev): 2 events per step, recorded after the input transform and after the GEMMs of a three-pass layer
 // pre (optional, training): kNumSlopes compact buffers that receive acc + bias of every activated layer
@@ -269,7 +351,7 @@ inline Form step_form(const Step &st, int f, int dt, int flags, const Plan &pl, 
 // flags: nd_flags of the call (ND_FLAG_NO_SPLITK: every tile whole; ND_FLAG_DIRECT_CONV: no Winograd form on any layer)
 int run_stack(int f, int act, int dt, const float *blob, const Plan &pl, hipStream_t s, int flags = 0, hipEvent_t *ev = nullptr,
               const QpBuf *pre = nullptr, const float *slopes = nullptr, const unsigned char *train_w1 = nullptr,
-              hipEvent_t *ev_x = nullptr) {
+              hipEvent_t *ev_x = nullptr, const Roi *rois = nullptr) {
     const BlobLayout bl = blob_layout(f, dt, pre == nullptr, pre != nullptr);
     const int cpp = nd_cpp(dt);
     int si = 0;
@@ -309,6 +391,12 @@ int run_stack(int f, int act, int dt, const float *blob, const Plan &pl, hipStre
         d.part_bytes = kSplitScratchBytes;
         d.nosplit = (flags & ND_FLAG_NO_SPLITK) != 0;
         const Form form = step_form(st, f, dt, flags, pl, bl, pre != nullptr, train_w1);
+        if (rois && rois[this_step].rows > 0) {
+            d.roi_r0 = rois[this_step].r0;
+            d.roi_c0 = rois[this_step].c0;
+            d.roi_rows = rois[this_step].rows;
+            d.roi_cols = rois[this_step].cols;
+        }
         // MaxPool2d(2) fused into the producing layer's epilogue where its kernel can (conv_w2d, three-pass output transform):
         // the pool kernel re-read the whole skip tensor from HBM (2.4 % of the fp32 conv stack)
         const bool next_is_pool = this_step + 1 < kNumSteps && kSteps[this_step + 1].layer < 0;

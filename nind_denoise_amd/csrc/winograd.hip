@@ -234,8 +234,9 @@ __global__ __launch_bounds__(128) void k_wino_output(const f32x4 *__restrict__ m
 //   input : pass 1 thread (tile, column j)  loads d[0..A)[j] (A lanes = 16 A contiguous bytes per tile row), column transform -> LDS
 //           pass 2 thread (row i, tile)     row transform of r[i][0..A), A position stores, each 512 B contiguous per half wave
 template <int T, int NTL>
-__global__ __launch_bounds__(NTL * (T + 2)) void k_wino_in2(const f32x4 *__restrict__ x, long xnp, int Hb, int Wb, int B, int TY, int TX,
-                                                            f32x4 *__restrict__ v, long vnp, long vbs) {
+__global__ __launch_bounds__(NTL * (T + 2)) void k_wino_in2(const f32x4 *__restrict__ x, long xnp, int Hb, int Wb, long img_stride, int row_stride, int B,
+                                                            int TY, int TX, f32x4 *__restrict__ v, long vnp, long vbs) {
+    // Hb x Wb: extent of the (view of the) bordered input a tile may read; img_stride / row_stride: of the buffer it lives in
     constexpr int A = Wino<T>::A, RS = A * A + 1;   // (+1: pass 2 reads a tile per lane, 16 (A*A+1) B apart: all banks)
     __shared__ f32x4 sm[NTL * RS];
     const long tiles = (long)B * TY * TX;
@@ -247,11 +248,11 @@ __global__ __launch_bounds__(NTL * (T + 2)) void k_wino_in2(const f32x4 *__restr
         const long t = t0 + tl;
         if (t < tiles) {
             const int tx = (int)(t % TX), ty = (int)((t / TX) % TY), b = (int)(t / ((long)TX * TY));
-            const f32x4 *src = x + (long)q * xnp + ((long)b * Hb + T * ty) * Wb + T * tx + j;
+            const f32x4 *src = x + (long)q * xnp + (long)b * img_stride + (long)(T * ty) * row_stride + T * tx + j;
             f32x4 d[A], o[A];
             const bool okj = T * tx + j < Wb;
 #pragma unroll
-            for (int i = 0; i < A; ++i) d[i] = (okj && T * ty + i < Hb) ? src[(long)i * Wb] : zero;
+            for (int i = 0; i < A; ++i) d[i] = (okj && T * ty + i < Hb) ? src[(long)i * row_stride] : zero;
             Wino<T>::bt(d, o);
 #pragma unroll
             for (int i = 0; i < A; ++i) sm[tl * RS + i * A + j] = o[i];
@@ -280,7 +281,7 @@ template <int T>
 __global__ __launch_bounds__(32 * (T + 2)) void k_wino_out2(const f32x4 *__restrict__ m, long mnp, long mbs, int B, int TY, int TX, int Hv,
                                                              int Wv, const float *__restrict__ bias, int act, float slope_imm,
                                                              const float *__restrict__ slope_dev, f32x4 *__restrict__ out, long onp,
-                                                             int out_plane0, int Ho, int Wo, int opad, f32x4 *__restrict__ pool, long pnp,
+                                                             int out_plane0, long out_img_stride, int Wo, int opad, f32x4 *__restrict__ pool, long pnp,
                                                              int Hp, int Wp, int ppad) {
     constexpr int A = Wino<T>::A, NTL = 32, RS = T * A + 1, NTH = 32 * A;
     __shared__ f32x4 sr[NTL * RS];
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(32 * (T + 2)) void k_wino_out2(const f32x4 *__restr
         if (tt >= tiles) continue;
         const int tx = (int)(tt % TX), ty = (int)((tt / TX) % TY), b = (int)(tt / ((long)TX * TY));
         const int xx = T * tx + pp % T, yy = T * ty + i;
-        if (xx < Wv && yy < Hv) dst[((long)b * Ho + yy + opad) * Wo + xx + opad] = so[i][pp];
+        if (xx < Wv && yy < Hv) dst[(long)b * out_img_stride + (long)(yy + opad) * Wo + xx + opad] = so[i][pp];
     }
     if (pool) {   // fused MaxPool2d(2): tiles start on even pixels and T is even, so every 2x2 block lies inside one tile
         f32x4 *pd = pool + (long)q * pnp;
@@ -368,10 +369,10 @@ struct WinoGeo {
     long vbs, mbs;       // position strides
     size_t v_bytes, m_bytes;
 };
-WinoGeo wino_geo(int T, const QpBuf &in, int cin, int cout) {
+WinoGeo wino_geo(int T, const QpBuf &in, int cin, int cout, int roi_rows = 0, int roi_cols = 0) {
     WinoGeo g;
-    g.Hv = in.Hb - 2;
-    g.Wv = in.Wb - 2;
+    g.Hv = roi_rows > 0 ? roi_rows : in.Hb - 2;
+    g.Wv = roi_rows > 0 ? roi_cols : in.Wb - 2;
     g.TY = (g.Hv + T - 1) / T;
     g.TX = (g.Wv + T - 1) / T;
     g.tiles = (long)in.B * g.TY * g.TX;
@@ -456,16 +457,22 @@ int nd_launch_conv_wino(int T, const ConvDesc &d, void *scratch, size_t scratch_
         ND_FAIL(ND_EINVAL, "winograd: fp32 3x3 layers only");
     if (d.cin % 16 || d.cout % 4) ND_FAIL(ND_EINVAL, "winograd: Cin must be a multiple of 16, Cout of 4 (got %d, %d)", d.cin, d.cout);
     if (d.pre) ND_FAIL(ND_EINVAL, "winograd: inference only (no pre-activation copy)");
-    const WinoGeo g = wino_geo(T, d.in, d.cin, d.cout);
-    if (d.out.Hb != g.Hv + 2 * d.out.pad || d.out.Wb != g.Wv + 2 * d.out.pad || d.out.B != d.in.B)
+    const bool roi = d.roi_rows > 0;
+    if (roi && (T != 6 || d.pool || d.roi_r0 < 0 || d.roi_c0 < 0 || d.roi_cols < 1 || d.roi_r0 + d.roi_rows > d.in.Hb - 2 || d.roi_c0 + d.roi_cols > d.in.Wb - 2))
+        ND_FAIL(ND_EINVAL, "winograd: region [%d,+%d) x [%d,+%d) outside the output (F(6x6), unpooled layers only)", d.roi_r0, d.roi_rows, d.roi_c0, d.roi_cols);
+    const WinoGeo g = wino_geo(T, d.in, d.cin, d.cout, d.roi_rows, d.roi_cols);
+    if (d.out.Hb != d.in.Hb - 2 + 2 * d.out.pad || d.out.Wb != d.in.Wb - 2 + 2 * d.out.pad || d.out.B != d.in.B)
         ND_FAIL(ND_EINVAL, "winograd: destination does not fit the result");
+    // a region is the same three passes on shifted base pointers (input view: rows [r0, r0 + rows + 2) of the bordered buffer)
+    const long roi_in = roi ? (long)d.roi_r0 * d.in.Wb + d.roi_c0 : 0, roi_out = roi ? (long)d.roi_r0 * d.out.Wb + d.roi_c0 : 0;
+    const int vHb = g.Hv + 2, vWb = g.Wv + 2;
     const size_t need = nd_wino_scratch_bytes(T, d.in, d.cin, d.cout);
     if (!scratch || scratch_bytes < need) ND_FAIL(ND_ENOMEM, "winograd: scratch %zu B given, %zu B needed", scratch_bytes, need);
     const int P = positions(T);
     f32x4 *v = (f32x4 *)scratch;
     f32x4 *m = (f32x4 *)((char *)scratch + ((g.v_bytes + 255) & ~(size_t)255));
     const int in_planes = 2 * nd_kblocks(d.cin), out_planes = d.cout / 4;
-    const f32x4 *x = (const f32x4 *)d.in.base + (long)d.in_plane0 * d.in.np();
+    const f32x4 *x = (const f32x4 *)d.in.base + (long)d.in_plane0 * d.in.np() + roi_in;
     dim3 gi((unsigned)((g.tiles + 255) / 256), in_planes);
     static const bool two_pass4 = getenv("ND_WINO_LDS4") != nullptr;   // A/B: the LDS-shared transform kernels for T = 4 too
     // tiles per workgroup of the LDS-shared input transform: 16 (measured on UtNet(64) at cs = 264: 16 and 64 equal on every layer;
@@ -475,13 +482,13 @@ int nd_launch_conv_wino(int T, const ConvDesc &d, void *scratch, size_t scratch_
     if (T == 2)
         hipLaunchKernelGGL(k_wino_input<2>, gi, dim3(256), 0, s, x, d.in.np(), d.in.Hb, d.in.Wb, d.in.B, g.TY, g.TX, v, g.vnp, g.vbs);
     else if (T == 6 && ntl == 16)
-        hipLaunchKernelGGL((k_wino_in2<6, 16>), gi2, dim3(128), 0, s, x, d.in.np(), d.in.Hb, d.in.Wb, d.in.B, g.TY, g.TX, v, g.vnp, g.vbs);
+        hipLaunchKernelGGL((k_wino_in2<6, 16>), gi2, dim3(128), 0, s, x, d.in.np(), vHb, vWb, (long)d.in.Hb * d.in.Wb, d.in.Wb, d.in.B, g.TY, g.TX, v, g.vnp, g.vbs);
     else if (T == 6 && ntl == 64)
-        hipLaunchKernelGGL((k_wino_in2<6, 64>), gi2, dim3(512), 0, s, x, d.in.np(), d.in.Hb, d.in.Wb, d.in.B, g.TY, g.TX, v, g.vnp, g.vbs);
+        hipLaunchKernelGGL((k_wino_in2<6, 64>), gi2, dim3(512), 0, s, x, d.in.np(), vHb, vWb, (long)d.in.Hb * d.in.Wb, d.in.Wb, d.in.B, g.TY, g.TX, v, g.vnp, g.vbs);
     else if (T == 6)
-        hipLaunchKernelGGL((k_wino_in2<6, 32>), gi2, dim3(256), 0, s, x, d.in.np(), d.in.Hb, d.in.Wb, d.in.B, g.TY, g.TX, v, g.vnp, g.vbs);
+        hipLaunchKernelGGL((k_wino_in2<6, 32>), gi2, dim3(256), 0, s, x, d.in.np(), vHb, vWb, (long)d.in.Hb * d.in.Wb, d.in.Wb, d.in.B, g.TY, g.TX, v, g.vnp, g.vbs);
     else if (two_pass4)
-        hipLaunchKernelGGL((k_wino_in2<4, 32>), gi2, dim3(192), 0, s, x, d.in.np(), d.in.Hb, d.in.Wb, d.in.B, g.TY, g.TX, v, g.vnp, g.vbs);
+        hipLaunchKernelGGL((k_wino_in2<4, 32>), gi2, dim3(192), 0, s, x, d.in.np(), vHb, vWb, (long)d.in.Hb * d.in.Wb, d.in.Wb, d.in.B, g.TY, g.TX, v, g.vnp, g.vbs);
     else
         hipLaunchKernelGGL(k_wino_input<4>, gi, dim3(256), 0, s, x, d.in.np(), d.in.Hb, d.in.Wb, d.in.B, g.TY, g.TX, v, g.vnp, g.vbs);
     ND_HIP(hipGetLastError());
@@ -522,7 +529,7 @@ int nd_launch_conv_wino(int T, const ConvDesc &d, void *scratch, size_t scratch_
 
     const float *bias = d.wpk + (size_t)P * gemm_floats(d.cin, d.cout);
     dim3 go((unsigned)((g.tiles + 127) / 128), out_planes);
-    f32x4 *out = (f32x4 *)d.out.base;
+    f32x4 *out = (f32x4 *)d.out.base + roi_out;
     f32x4 *pool = nullptr;
     long pnp = 0;
     int Hp = 0, Wp = 0, ppad = 0;
@@ -539,10 +546,10 @@ int nd_launch_conv_wino(int T, const ConvDesc &d, void *scratch, size_t scratch_
     dim3 go2((unsigned)((g.tiles + 31) / 32), out_planes);
     if (T == 6)
         hipLaunchKernelGGL(k_wino_out2<6>, go2, dim3(256), 0, s, (const f32x4 *)m, g.mnp, g.mbs, d.in.B, g.TY, g.TX, g.Hv, g.Wv, bias,
-                           d.act, d.slope, d.slope_dev, out, d.out.np(), d.out_plane0, d.out.Hb, d.out.Wb, d.out.pad, pool, pnp, Hp, Wp, ppad);
+                           d.act, d.slope, d.slope_dev, out, d.out.np(), d.out_plane0, (long)d.out.Hb * d.out.Wb, d.out.Wb, d.out.pad, pool, pnp, Hp, Wp, ppad);
     else if (T == 4 && two_pass4)
         hipLaunchKernelGGL(k_wino_out2<4>, go2, dim3(192), 0, s, (const f32x4 *)m, g.mnp, g.mbs, d.in.B, g.TY, g.TX, g.Hv, g.Wv, bias,
-                           d.act, d.slope, d.slope_dev, out, d.out.np(), d.out_plane0, d.out.Hb, d.out.Wb, d.out.pad, pool, pnp, Hp, Wp, ppad);
+                           d.act, d.slope, d.slope_dev, out, d.out.np(), d.out_plane0, (long)d.out.Hb * d.out.Wb, d.out.Wb, d.out.pad, pool, pnp, Hp, Wp, ppad);
     else if (T == 2)
         hipLaunchKernelGGL(k_wino_output<2>, go, dim3(128), 0, s, (const f32x4 *)m, g.mnp, g.mbs, d.in.B, g.TY, g.TX, g.Hv, g.Wv, bias,
                            d.act, d.slope, d.slope_dev, out, d.out.np(), d.out_plane0, d.out.Hb, d.out.Wb, d.out.pad, pool, pnp, Hp, Wp, ppad);

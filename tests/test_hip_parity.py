@@ -521,8 +521,12 @@ def test_frame_end_to_end_vs_oracle(dev, whole_k):
 
     ref = otiler.denoise_frame(frame, cs, ucs, ol, model_fn, batch=4)
     img = torch.from_numpy(frame).to(dev)
+    out_roi = pipeline.denoise_frame(net, img, cs, ucs, ol, batch=5)    # default: only what the useful tile centres depend on
+    assert_close(out_roi, torch.from_numpy(ref), "frame e2e")
+    net.useful_only = False                                             # whole tiles in every layer, as forward() computes them
     out = pipeline.denoise_frame(net, img, cs, ucs, ol, batch=5)
-    assert_close(out, torch.from_numpy(ref), "frame e2e")
+    assert_close(out, torch.from_numpy(ref), "frame e2e, whole tiles")
+    assert (out - out_roi).abs().max().item() <= 2e-6 * max(1.0, out.abs().max().item())
     out2 = pipeline.denoise_frame(lambda x: net(x), img, cs, ucs, ol, batch=5)
     assert torch.equal(out, out2), "fused gather/stitch path differs from the unfused one"
     # a different batch size only changes how tiles are grouped, never the result
@@ -754,9 +758,12 @@ def test_frame_half_storage_fused_equals_unfused(dev, dtype, whole_k):
     net.load_state_dict(synth.make_utnet_state_dict(funit=16, seed=9))
     net = net.to(dev).set_compute_dtype(dtype)
     img = torch.from_numpy(synth.make_frame(333, 290, seed=3)).to(dev)
+    a_roi = pipeline.denoise_frame(net, img, 120, 88, 16, batch=5)
+    net.useful_only = False        # bit-for-bit equality holds between the two WHOLE-tile paths (fused / forward + stitch)
     a = pipeline.denoise_frame(net, img, 120, 88, 16, batch=5)
     b = pipeline.denoise_frame(lambda x: net(x), img, 120, 88, 16, batch=3)
     assert torch.equal(a, b)
+    assert (a - a_roi).abs().max().item() <= 1e-6 * max(1.0, a.abs().max().item())
     net.set_compute_dtype("f32")
     c = pipeline.denoise_frame(net, img, 120, 88, 16, batch=5)
     rel = ((a - c).abs().max() / c.abs().max()).item()
@@ -823,8 +830,12 @@ def test_reference_style_main_loop_with_dataloader(dev, whole_k):
             newimg[:, ay:ay + t.shape[1], ax:ax + t.shape[2]] += t
             n += 1
     assert n == len(ds)
+    net.useful_only = False        # the reference loop calls forward(): whole tiles; the fused loop matches it bit for bit in that mode
     fused = pipeline.denoise_frame(net, torch.from_numpy(frame).to(dev), cs, ucs, ol, batch=7)
     assert torch.equal(newimg, fused)
+    net.useful_only = True         # default: the last decoder levels restricted to what the useful centres need -- same canvas
+    fused_roi = pipeline.denoise_frame(net, torch.from_numpy(frame).to(dev), cs, ucs, ol, batch=7)
+    assert (fused_roi - fused).abs().max().item() <= 2e-6 * max(1.0, fused.abs().max().item())
 
 
 def test_api_error_paths(dev):

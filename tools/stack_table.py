@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--crop", type=int, default=0, help="margin of the useful tile centre ((cs - ucs) / 2 of the denoise loop); 0: whole tiles")
     a = ap.parse_args()
     from nind_denoise_amd.networks.UtNet import UtNet
     torch.manual_seed(123)
@@ -30,7 +31,7 @@ def main():
     net.split_k = not (a.flags & 1)
     net.winograd = not (a.flags & 2)
     net.w1d_regs = bool(a.flags & 4)
-    steps = bench.conv_stack_profile(net, a.cs, a.batch, dev, reps=a.reps)
+    steps = bench.conv_stack_profile(net, a.cs, a.batch, dev, reps=a.reps, crop=a.crop)
     tot = 0.0
     print(f"{'layer':12s} {'form':12s} {'ms':>8s} {'xf_in':>7s} {'TB/s':>5s} {'gemm':>7s} {'xf_out':>7s} {'TB/s':>5s} {'exec TF':>8s} {'alg TF':>8s}")
     for s in steps:
