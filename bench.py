@@ -96,6 +96,9 @@ def parse():
     ap.add_argument("--no-winograd", action="store_true", help="direct convolution on every layer (A/B switch)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the host->host (PCIe-inclusive) measurement")
+    ap.add_argument("--whole-tiles", action="store_true",
+                    help="compute every layer on the whole tile, as UtNet.forward does (ND_FLAG_FULL_TILES); default: the last decoder "
+                         "levels compute only what the useful centre [pad, cs - pad) of a tile depends on -- same canvas")
     return ap.parse_args()
 
 
@@ -344,6 +347,7 @@ def main():
     net.load_state_dict(sd)
     net = net.eval().to(dev).set_compute_dtype(args.dtype)
     net.winograd = not args.no_winograd
+    net.useful_only = not args.whole_tiles
     blob = net.packed_weights(dev)
     if world > 1 and not REHEARSAL:
         dist.broadcast(blob, src=0)  # one-time weight broadcast (rank 0 is the model owner)
@@ -435,7 +439,10 @@ def main():
         "config": {
             "workload": f"configs[{cfg_idx}]: {what}, {args.dtype} storage in the conv stack (fp32 accumulate), UtNet(funit={args.funit},PReLU) "
                         f"random-init (seed 123), cs={cs} (nearest valid to the named size; the reference rejects 256 / 512) ucs={ucs} ol={ol} -> "
-                        f"{total} tiles/frame, tiles per conv-stack launch {args.batch}, crop->infer->stitch device resident (frame and canvas in HBM)",
+                        f"{total} tiles/frame, tiles per conv-stack launch {args.batch}, crop->infer->stitch device resident (frame and canvas in HBM)"
+                        + ("" if args.whole_tiles else "; every tile's input is the whole cs x cs crop, and the layers of the last decoder levels compute "
+                           "only the outputs that the tile's useful centre (the part the stitch keeps, denoise_image.py:249-258) depends on -- the canvas "
+                           "is the same as with whole-tile layers (key `whole_tiles`)"),
             "tiles_per_frame": total,
             "frames_per_step": frames_per_step,
             "flop_per_frame": net.flops_per_tile(cs) * total,
@@ -452,6 +459,27 @@ def main():
             steps = conv_stack_profile(net, cs, b, dev, crop=(cs - ucs) // 2)
             log("conv stack profile done")
             out["roofline"] = roofline_report(steps, args.dtype, cs, b, args.funit)
+            out["config"]["computed_flop_per_frame"] = sum(s_["flop"] for s_ in steps) / b * total   # conv stack, regions counted as computed
+        if world == 1 and not args.whole_tiles and args.frames == 0:
+            # the same frame with every layer on whole tiles (what UtNet.forward computes): its rate, and the two canvases compared
+            cv_roi = canvas.clone()
+            net.useful_only = False
+            step()
+            torch.cuda.synchronize()
+            tw = time.perf_counter()
+            nw = max(2, min(4, args.steps))
+            for _ in range(nw):
+                step()
+            torch.cuda.synchronize()
+            tw = time.perf_counter() - tw
+            diff = float((canvas - cv_roi).abs().max().item())
+            out["whole_tiles"] = {"value": round(mp * nw / tw, 4), "unit": "MP/s", "frames": nw,
+                                  "canvas_max_abs_diff": diff, "canvas_max_abs": float(cv_roi.abs().max().item()),
+                                  "note": "ND_FLAG_FULL_TILES: every layer computes its whole tile; canvas_max_abs_diff = max |canvas - canvas of the "
+                                          "timed (useful-region) loop| over the whole frame"}
+            net.useful_only = True
+            del cv_roi
+            log(f"whole-tile leg: {out['whole_tiles']['value']} MP/s, canvases differ by {diff:.2e}")
         if not args.no_host_leg and world == 1:
             # SURVEY.md 8(d)'s end-to-end definition: decoded fp32 frame in pinned host memory -> stitched frame in host memory,
             # through the resident engine (H2D / compute / D2H overlapped over a ring of 3 slots).  Reported beside `value`.
