@@ -96,6 +96,7 @@ def parse():
     ap.add_argument("--no-winograd", action="store_true", help="direct convolution on every layer (A/B switch)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the host->host (PCIe-inclusive) measurement")
+    ap.add_argument("--no-whole-leg", action="store_true", help="skip the comparison leg that runs the same frame with whole-tile layers")
     ap.add_argument("--whole-tiles", action="store_true",
                     help="compute every layer on the whole tile, as UtNet.forward does (ND_FLAG_FULL_TILES); default: the last decoder "
                          "levels compute only what the useful centre [pad, cs - pad) of a tile depends on -- same canvas")
@@ -460,7 +461,7 @@ def main():
             log("conv stack profile done")
             out["roofline"] = roofline_report(steps, args.dtype, cs, b, args.funit)
             out["config"]["computed_flop_per_frame"] = sum(s_["flop"] for s_ in steps) / b * total   # conv stack, regions counted as computed
-        if world == 1 and not args.whole_tiles and args.frames == 0:
+        if world == 1 and not args.whole_tiles and args.frames == 0 and not args.no_whole_leg:
             # the same frame with every layer on whole tiles (what UtNet.forward computes): its rate, and the two canvases compared
             cv_roi = canvas.clone()
             net.useful_only = False
