@@ -15,6 +15,11 @@ frame is split into N contiguous shards; inside the timed region rank 0 sends ev
 point-to-point over xGMI), every rank denoises its shard into its own canvas and rank 0 receives and adds the canvas row bands
 (nind_denoise_amd/dist.py): total work per step is fixed -> "strong".
 
+The timed loop is the product's default: every tile's whole cs x cs crop goes in, every layer runs, and the layers of the last
+decoder levels compute only the outputs that the tile's useful centre (what the stitch keeps) depends on; `--whole-tiles` times
+the loop with whole-tile layers instead, and the default run reports that rate and the difference of the two canvases under
+`whole_tiles`.
+
 One JSON line on rank 0:
   roofline      the dominant kernel by time (conv_w2d, the fused 1-D Winograd 3x3 kernel on the fp32 path): MFMA-EXECUTED
                 FLOP / HIP-event time on the launch stream / MFMA peak (<= 1 by construction); the algorithmic
