@@ -362,6 +362,9 @@ int nd_launch_conv(const ConvDesc &d, hipStream_t stream) {
     p.n_tiles_m = (M + V.mblk - 1) / V.mblk;
     p.tiles_per_problem = p.n_tiles_n * p.n_tiles_m;
     p.wpx = 0;
+    // gap-free 1-tap launch with raw output (the Winograd GEMMs): see ConvParams::linear
+    p.linear = taps == 1 && !up && dt == ND_F32 && d.in.pad == 0 && d.out.pad == 0 && d.out.Hb == d.in.Hb && d.out.Wb == d.in.Wb && cross &&
+               d.act == ND_ACT_NONE && d.nbatch > 1 && !d.pre && !roi;
     p.in_bs = d.in_bs;
     p.out_bs = d.out_bs;
     p.w_bs = (long)d.w_bs;
