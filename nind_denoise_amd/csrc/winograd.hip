@@ -20,6 +20,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+// tile index -> (column, row, image); the launcher keeps the tile count below 2^31, so one 32-bit division pair instead of three
+// 64-bit ones (a 64-bit division is ~100 VALU instructions per thread)
+__device__ __forceinline__ void tile_pos(long t, int TX, int TY, int &tx, int &ty, int &b) {
+    const unsigned u = (unsigned)t, row = u / (unsigned)TX;
+    tx = (int)(u - row * (unsigned)TX);
+    b = (int)(row / (unsigned)TY);
+    ty = (int)(row - (unsigned)b * (unsigned)TY);
+}
+
 template <int T> struct Wino;
 template <> struct Wino<2> {
     static constexpr int A = 4;
@@ -116,7 +125,8 @@ __global__ __launch_bounds__(256) void k_wino_input(const f32x4 *__restrict__ x,
     const long tiles = (long)B * TY * TX;
     if (t >= tiles) return;
     const int q = blockIdx.y;
-    const int tx = (int)(t % TX), ty = (int)((t / TX) % TY), b = (int)(t / ((long)TX * TY));
+    int tx, ty, b;
+    tile_pos(t, TX, TY, tx, ty, b);
     const f32x4 *src = x + (long)q * xnp + ((long)b * Hb + T * ty) * Wb + T * tx;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 d[A][A], r[A][A];
@@ -197,7 +207,8 @@ __global__ __launch_bounds__(128) void k_wino_output(const f32x4 *__restrict__ m
             }
         }
         if (pool) {   // fused MaxPool2d(2): a tile's T x T outputs hold (T/2)^2 whole 2x2 blocks (T even, tiles start on even pixels)
-            const int tx = (int)(t % TX), ty = (int)((t / TX) % TY), b = (int)(t / ((long)TX * TY));
+            int tx, ty, b;
+    tile_pos(t, TX, TY, tx, ty, b);
             f32x4 *pd = pool + (long)q * pnp + (long)b * Hp * Wp;
 #pragma unroll
             for (int a = 0; a < T / 2; ++a)
@@ -220,7 +231,8 @@ __global__ __launch_bounds__(128) void k_wino_output(const f32x4 *__restrict__ m
         const long tt = t0 + p / T;
         if (tt >= tiles) break;
         const int j = p % T;
-        const int tx = (int)(tt % TX), ty = (int)((tt / TX) % TY), b = (int)(tt / ((long)TX * TY));
+        int tx, ty, b;
+        tile_pos(tt, TX, TY, tx, ty, b);
         const int x = T * tx + j;
         if (x >= Wv) continue;
 #pragma unroll
@@ -247,7 +259,8 @@ __global__ __launch_bounds__(NTL * (T + 2)) void k_wino_in2(const f32x4 *__restr
         const int tl = threadIdx.x / A, j = threadIdx.x % A;
         const long t = t0 + tl;
         if (t < tiles) {
-            const int tx = (int)(t % TX), ty = (int)((t / TX) % TY), b = (int)(t / ((long)TX * TY));
+            int tx, ty, b;
+    tile_pos(t, TX, TY, tx, ty, b);
             const f32x4 *src = x + (long)q * xnp + (long)b * img_stride + (long)(T * ty) * row_stride + T * tx + j;
             f32x4 d[A], o[A];
             const bool okj = T * tx + j < Wb;
@@ -334,7 +347,8 @@ __global__ __launch_bounds__(32 * (T + 2)) void k_wino_out2(const f32x4 *__restr
         const int i = idx / (NTL * T), pp = idx - i * (NTL * T);
         const long tt = t0 + pp / T;
         if (tt >= tiles) continue;
-        const int tx = (int)(tt % TX), ty = (int)((tt / TX) % TY), b = (int)(tt / ((long)TX * TY));
+        int tx, ty, b;
+        tile_pos(tt, TX, TY, tx, ty, b);
         const int xx = T * tx + pp % T, yy = T * ty + i;
         if (xx < Wv && yy < Hv) dst[(long)b * out_img_stride + (long)(yy + opad) * Wo + xx + opad] = so[i][pp];
     }
@@ -345,7 +359,8 @@ __global__ __launch_bounds__(32 * (T + 2)) void k_wino_out2(const f32x4 *__restr
             const int tl = pp / (T / 2), c = pp % (T / 2);
             const long tt = t0 + tl;
             if (tt >= tiles) continue;
-            const int tx = (int)(tt % TX), ty = (int)((tt / TX) % TY), b = (int)(tt / ((long)TX * TY));
+            int tx, ty, b;
+        tile_pos(tt, TX, TY, tx, ty, b);
             const int px = tx * (T / 2) + c, py = ty * (T / 2) + a;
             if (2 * px + 1 < Wv && 2 * py + 1 < Hv) {
                 const f32x4 p00 = so[2 * a][tl * T + 2 * c], p01 = so[2 * a][tl * T + 2 * c + 1];
@@ -468,6 +483,7 @@ int nd_launch_conv_wino(int T, const ConvDesc &d, void *scratch, size_t scratch_
     const int vHb = g.Hv + 2, vWb = g.Wv + 2;
     const size_t need = nd_wino_scratch_bytes(T, d.in, d.cin, d.cout);
     if (!scratch || scratch_bytes < need) ND_FAIL(ND_ENOMEM, "winograd: scratch %zu B given, %zu B needed", scratch_bytes, need);
+    if (g.tiles >= (1L << 31)) ND_FAIL(ND_EINVAL, "winograd: %ld tiles exceed the 32-bit tile index", g.tiles);
     const int P = positions(T);
     f32x4 *v = (f32x4 *)scratch;
     f32x4 *m = (f32x4 *)((char *)scratch + ((g.v_bytes + 255) & ~(size_t)255));
