@@ -260,6 +260,15 @@ static int pick_variant(const ConvDesc &d, int M) {
     return g0 + 4;
 }
 
+// does a layer restricted to the region d.roi_* have a workgroup shape whose LDS stage images fit?  (a region much narrower than the
+// buffer's rows puts many row gaps into the linear pixel range of an N tile)
+bool nd_conv_roi_fits(const ConvDesc &d) {
+    const bool up = d.kind == ND_CONVT2S2;
+    const int v = pick_variant(d, up ? 4 * d.cout : d.cout);
+    if (v < 0 || v >= g_nvariants) return false;
+    return variant_lds(variant_at(v), d.in, nullptr, nullptr, d.roi_rows > 0 ? d.roi_rows : 0, d.roi_rows > 0 ? d.roi_cols : 0) <= kMaxLds;
+}
+
 static int g_lds_set[16][64] = {{0}};   // per device: function attributes belong to the device's copy of the code object
 
 int nd_launch_conv(const ConvDesc &d, hipStream_t stream) {

@@ -81,6 +81,7 @@ struct ConvDesc {
 // scratch that lets every layer split its partial round: 512 work items of 64 x 1024 accumulators
 static const size_t kSplitScratchBytes = (size_t)512 * 64 * 1024 * 4;
 int nd_launch_conv(const ConvDesc &d, hipStream_t stream);
+bool nd_conv_roi_fits(const ConvDesc &d);   // a launch restricted to d.roi_* finds a workgroup shape that fits the LDS
 static inline int nd_launch_conv_f32(const ConvDesc &d, hipStream_t stream) { return nd_launch_conv(d, stream); }
 int nd_conv_variant_count();
 int nd_conv_variant_gemm(int cin, int cout);   // 1-tap fp32 variant (256- / 128-row workgroup tiles) for a Winograd GEMM

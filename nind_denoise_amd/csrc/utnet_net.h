@@ -337,7 +337,25 @@ inline bool rois_supported(int f, int dt, int flags, const Plan &pl, const BlobL
     for (int i = 0; i < kNumSteps; ++i) {
         if (rois[i].rows <= 0) continue;
         const Form form = step_form(kSteps[i], f, dt, flags, pl, bl, false, nullptr);
-        if (form == FORM_DIRECT || form == FORM_WINO3P) continue;
+        if (form == FORM_DIRECT) {
+            // conv_qp walks linear pixel ranges: a region much narrower than its buffer may not fit any stage image -- then no
+            // layer is restricted (a whole-tile layer needs whole-tile producers)
+            const LayerSpec &l = kLayers[kSteps[i].layer];
+            ConvDesc d;
+            d.kind = l.kind;
+            d.cin = lcin(l, f);
+            d.cout = lcout(l, f);
+            d.in = pl.buf[kSteps[i].src];
+            d.out = pl.buf[kSteps[i].dst];
+            d.variant = -1;
+            d.roi_r0 = rois[i].r0;
+            d.roi_c0 = rois[i].c0;
+            d.roi_rows = rois[i].rows;
+            d.roi_cols = rois[i].cols;
+            if (!nd_conv_roi_fits(d)) return false;
+            continue;
+        }
+        if (form == FORM_WINO3P) continue;
         if (form == FORM_W1D4 && !(flags & ND_FLAG_W1D_REGS)) continue;
         return false;
     }

@@ -30,6 +30,8 @@ def _net(funit, dev, dtype="f32", seed=11):
     (64, 640, 420, 264, 200, 64, 12),     # production width: three-pass F(6x6) layers with regions
     (64, 900, 600, 504, 480, 6, 4),       # the shipped default tiling (margin 12)
     (16, 520, 400, 248, 201, 32, 6),      # odd cs - ucs: pad = 23, useful width ucs + 1
+    (16, 150, 110, 136, 16, 4, 9),        # a useful centre of 16 pixels in a 136-pixel tile: regions shrink to a few pixels at every level
+    (64, 300, 280, 104, 96, 8, 5),        # margin 4 at the smallest tile: regions touch the borders
 ])
 def test_useful_region_canvas_equals_whole_tiles_and_oracle(dev, funit, W, H, cs, ucs, ol, batch):
     from oracle import networks as onet
