@@ -68,3 +68,32 @@ def test_useful_region_half_storage(dev, dtype):
     full = pipeline.denoise_frame(net, img, 264, 200, 64, batch=6).cpu().numpy()
     # direct kernels on both paths: a pixel's K loop is the same, only its tile / lane differs
     assert np.abs(roi - full).max() <= 1e-6 * max(1.0, float(np.abs(full).max())), np.abs(roi - full).max()
+
+
+def test_useful_region_random_geometries(dev):
+    # seeded sweep: tile sizes of the form 16k + 56, useful sizes / overlaps / frame sizes / batch sizes at random (incl. frames barely
+    # larger than a tile and margins from 1 pixel to a third of the tile): the useful-region canvas must equal the whole-tile canvas
+    rng = np.random.default_rng(20260105)
+    nets = {(16, "f32"): _net(16, dev)[0], (64, "f32"): _net(64, dev)[0], (16, "bf16"): _net(16, dev, "bf16")[0]}
+    for case in range(14):
+        funit, dtype = [(16, "f32"), (64, "f32"), (16, "bf16")][case % 3]
+        cs = 56 + 16 * int(rng.integers(3, 11 if funit == 16 else 9))
+        margin = int(rng.integers(1, cs // 3))
+        ucs = cs - 2 * margin - int(rng.integers(0, 2))
+        ol = int(rng.integers(0, max(1, min(ucs - 1, 2 * margin + 1))))
+        W = cs + int(rng.integers(1, 2 * cs))        # (the tiler refuses frames smaller than its mirror padding)
+        H = cs + int(rng.integers(1, cs))
+        batch = int(rng.integers(1, 12))
+        net = nets[(funit, dtype)]
+        # 16-bit storage: with the split-K tail on, a re-associated fp32 sum may round to the neighbouring bf16 value and the two
+        # canvases drift by ~1e-4; with whole-K tiles a pixel's sum does not depend on the launch and the canvases must be identical
+        net.split_k = dtype == "f32"
+        img = torch.from_numpy(synth.make_frame(W, H, seed=case)).to(dev)
+        net.useful_only = True
+        roi = pipeline.denoise_frame(net, img, cs, ucs, ol, batch=batch)
+        net.useful_only = False
+        full = pipeline.denoise_frame(net, img, cs, ucs, ol, batch=batch)
+        net.useful_only = True
+        scale = max(1.0, float(full.abs().max().item()))
+        err = float((roi - full).abs().max().item())
+        assert torch.isfinite(roi).all() and err <= (3e-6 * scale if dtype == "f32" else 0.0), (case, funit, dtype, W, H, cs, ucs, ol, batch, err)
