@@ -378,6 +378,7 @@ int nd_launch_conv(const ConvDesc &d, hipStream_t stream) {
     p.out_bs = d.out_bs;
     p.w_bs = (long)d.w_bs;
     if (d.nbatch > 1 && d.pre) ND_FAIL(ND_EINVAL, "conv: a batched launch keeps no pre-activation copy");
+    nd_conv_fastdivs(p);
     const long ntiles = (long)p.tiles_per_problem * (d.nbatch > 1 ? d.nbatch : 1);
     const int per_cu = lds * 2 <= kMaxLds && V.threads <= 256 ? 2 : 1;
     const long slots = (long)g_num_cus * per_cu;

@@ -127,9 +127,9 @@ __global__ __launch_bounds__(512) void conv_w2d(ConvParams p) {
         const unsigned u = (unsigned)nb * kS + s;
         r.ok = u < tot;
         const unsigned uc = r.ok ? u : tot - 1;
-        r.img = (int)(uc / (unsigned)p.PV);
+        r.img = (int)fdiv(uc, p.fd_PV);
         const int rem = (int)(uc - (unsigned)r.img * p.PV);
-        const int band = rem / p.Wv;
+        const int band = (int)fdiv((unsigned)rem, p.fd_Wv);
         r.y0 = band * kR;
         r.x0 = 4 * (rem - band * p.Wv);
         return r;
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(512) void conv_w2d(ConvParams p) {
         const Item it = decode(w);
         f_c = it.c0;
         f_end = it.c1;
-        const int nb = it.tile / p.n_tiles_m, mb = it.tile - nb * p.n_tiles_m;
+        const int nb = (int)fdiv((unsigned)it.tile, p.fd_ntm), mb = it.tile - nb * p.n_tiles_m;
         f_w = p.wpk + (size_t)mb * kMTB * p.KB * kTaps * 256;     // wave-uniform: the lane's 16 bytes are added as a 32-bit offset
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps)
@@ -289,13 +289,13 @@ __global__ __launch_bounds__(512) void conv_w2d(ConvParams p) {
     const int e_row = lane >> 4, e_px = lane & 15;                  // reader side: rows e_row and e_row + 4, pixel e_px of the wave's 16
     f32x4 biasq[4];                                                 // bias of channels 8g + 4h .. + 3 of this wave's M tile
     auto load_bias = [&](int id) {
-        const int mb = id % p.n_tiles_m;
+        const int mb = id - (int)fdiv((unsigned)id, p.fd_ntm) * p.n_tiles_m;
 #pragma unroll
         for (int g = 0; g < 4; ++g) biasq[g] = *(const f32x4 *)(p.bias + (mb * kMTB + wm) * 32 + 8 * g + 4 * h);
     };
     load_bias(decode(vb).tile);
     auto epilogue = [&](int id, auto fast) {
-        const int nb = id / p.n_tiles_m, mb = id - nb * p.n_tiles_m;
+        const int nb = (int)fdiv((unsigned)id, p.fd_ntm), mb = id - nb * p.n_tiles_m;
         const Strip st = strip_of(nb, 4 * wn + (e_px >> 2));        // the strip this lane STORES for
         const int ex = st.x0 + (e_px & 3);
         const unsigned offA = (unsigned)((st.img * p.Po + (st.y0 + e_row + p.opad) * p.Wo + ex + p.opad) * 16);   // bytes inside a plane (< 2^32)
@@ -620,6 +620,7 @@ int nd_launch_conv_w2d(const ConvDesc &d, hipStream_t stream) {
     p.n_tiles_n = (int)(((long)p.nimg * p.PV + kS - 1) / kS);
     p.n_tiles_m = (d.cout + kMTB * 32 - 1) / (kMTB * 32);
     p.tiles_per_problem = p.n_tiles_n * p.n_tiles_m;
+    nd_conv_fastdivs(p);
     const long ntiles = p.tiles_per_problem;
     const long slots = cus[dev];
     // (a layer with a fused pool keeps every tile whole: the split-K finish kernel has no view of a tile's 2x2 neighbours)
