@@ -157,6 +157,10 @@ typedef struct nd_step_profile {
 int nd_utnet_profile_stack(int funit, int act, int dtype, int flags, const void *packed_dev, int batch, int cs, int crop,
                            void *workspace, size_t workspace_bytes, void *stream, nd_step_profile *steps, int max_steps);
 const char *nd_utnet_step_name(int i);
+/* host-only: region {r0, c0, rows, cols} of stack step `step` that nd_utnet_denoise_tiles computes when the centre [crop, cs - crop)
+ * of a tile is kept (output grid of a 3x3 layer, input grid of a 2x2 stride-2 transpose; zeros: the whole tensor); returns the number
+ * of restricted steps (>= 0) or a negative nd_status */
+int nd_utnet_useful_region(int funit, int cs, int crop, int step, int *rect);
 
 /* ---------------------------------------------------------------- UNet (ThirdPartyNets.py:62-169, eval mode)
  * Same contract as the UtNet entry points; BatchNorm2d running statistics are folded into the convolutions when the

@@ -66,6 +66,7 @@ _SIGNATURES = {
     "nd_utnet_flops": (c_double, [c_int, c_int]),
     "nd_utnet_profile_stack": (c_int, [c_int] * 4 + [c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_int]),
     "nd_utnet_step_name": (c_char_p, [c_int]),
+    "nd_utnet_useful_region": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_int)]),
     "nd_layer_packed_bytes": (c_size_t, [c_int] * 4),
     "nd_layer_pack": (c_int, [c_int] * 4 + [c_void_p, c_void_p, c_void_p, c_size_t]),
     "nd_layer_workspace_bytes": (c_size_t, [c_int] * 7),

@@ -279,6 +279,24 @@ extern "C" int nd_utnet_profile_stack(int funit, int act, int dtype, int flags, 
     return rc;
 }
 
+// Host-only query (no GPU call): the region of step i that nd_utnet_denoise_tiles computes when only the centre
+// [crop, cs - crop) of a tile is kept -- rect = {r0, c0, rows, cols} on the layer's output grid (3x3 layers) or input grid
+// (2x2 stride-2 transposes), all zero where the step computes its whole tensor.  Returns the number of restricted steps.
+extern "C" int nd_utnet_useful_region(int funit, int cs, int crop, int step, int *rect) {
+    if (!valid_cs(cs) || funit <= 0 || step < 0 || step >= kNumSteps || !rect || crop < 0 || 2 * crop >= cs)
+        ND_FAIL(ND_EINVAL, "nd_utnet_useful_region: bad arguments");
+    const Plan pl = make_plan(funit, cs, cs, 1, 1, nullptr, ND_F32);
+    Roi rois[kNumSteps];
+    plan_rois(pl, crop, crop, rois);
+    int n = 0;
+    for (int i = 0; i < kNumSteps; ++i) n += rois[i].rows > 0;
+    rect[0] = rois[step].r0;
+    rect[1] = rois[step].c0;
+    rect[2] = rois[step].rows;
+    rect[3] = rois[step].cols;
+    return n;
+}
+
 extern "C" const char *nd_utnet_step_name(int i) {
     if (i < 0 || i >= kNumSteps) return nullptr;
     return kSteps[i].layer >= 0 ? kLayers[kSteps[i].layer].key : "maxpool";

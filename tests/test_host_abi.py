@@ -236,3 +236,47 @@ def test_read_16bit_png_of_the_reference(golden_dir):
     assert img.dtype == np.float32 and img.shape == (3, 144, 144)
     assert np.array_equal(img, raw[:, :, :3].transpose(2, 0, 1).astype(np.float32) / 65535)
     assert 0.0 <= img.min() and img.max() <= 1.0
+
+
+@pytest.mark.parametrize("cs,ucs", [(264, 200), (504, 480), (520, 456), (248, 201), (136, 16), (104, 96)])
+def test_useful_regions_equal_receptive_field_backprojection(cs, ucs):
+    """nd_utnet_useful_region (the regions the fused loop restricts the decoder layers to) against an independent restatement:
+    project the kept centre [pad, cs - pad) backwards through the layer list of UtNet.py:97-109 (ZeroPad2d(-2) + 1x1, transposed 3x3
+    layers grow the needed interval by 2 on the low side, 2x2 stride-2 transposes halve it)."""
+    import ctypes
+    lib = _lib.load()
+    crop = int((cs - ucs) / 2)
+    names = [lib.nd_utnet_step_name(i).decode() for i in range(26)]
+    # sizes of the decoder tensors for a cs x cs tile (valid convolutions / transposed convolutions of UtNet)
+    l1 = cs
+    l2 = l1 // 2 - 4
+    l3 = l2 // 2 - 4
+    l4 = l3 // 2 - 4
+    out_size = {"tconvs4.2": l1 + 4, "tconvs4.0": l1 + 2, "tconvs3.2": l2 + 4, "tconvs3.0": l2 + 2, "tconvs2.2": l3 + 4, "tconvs2.0": l3 + 2,
+                "tconvs1.2": l4 + 4, "tconvs1.0": l4 + 2}
+    up_in = {"up4": l2 + 4, "up3": l3 + 4, "up2": l4 + 4, "up1": l4 // 2}
+    want = {}
+    lo, hi = crop + 2, cs - crop + 2                       # rows of tconvs4.2's output that the final 1x1 + crop reads
+    for lvl in (4, 3, 2, 1):
+        for name in (f"tconvs{lvl}.2", f"tconvs{lvl}.0"):
+            size = out_size[name]
+            a, b = max(lo, 0), min(hi, size)
+            want[name] = None if (a, b) == (0, size) else (a, b - a)
+            lo, hi = max(a - 2, 0), min(b, size - 2)       # input rows (interior) a transposed 3x3 layer needs
+        size = up_in[f"up{lvl}"]
+        a, b = lo >> 1, min((hi + 1) >> 1, size)
+        want[f"up{lvl}"] = None if (a, b) == (0, size) else (a, b - a)
+        lo, hi = a, b
+    rect = (ctypes.c_int * 4)()
+    restricted = 0
+    for i, name in enumerate(names):
+        n = lib.nd_utnet_useful_region(64, cs, crop, i, rect)
+        assert n >= 0, lib.nd_last_error()
+        got = tuple(rect)
+        if name in want and want[name] is not None:
+            r0, rows = want[name]
+            assert got == (r0, r0, rows, rows), (name, got, want[name])
+            restricted += 1
+        else:
+            assert got == (0, 0, 0, 0), (name, got)           # encoder, pools and fully needed decoder layers: whole tensors
+    assert n == restricted
