@@ -557,9 +557,10 @@ int nd_launch_conv_w2d(const ConvDesc &d, hipStream_t stream) {
         cus[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     const int lds = kLds;
-    // timing ablations (tools/w2d_ablate.sh; ND_W2D_DBG names one of the instantiated masks): never set in production
-    static const int dbg_env = getenv("ND_W2D_DBG") ? atoi(getenv("ND_W2D_DBG")) : 0;
     void (*fn)(ConvParams) = conv_w2d<0>;
+#ifdef ND_QP_STAMPS
+    // diagnostic build only (make STAMPS=1; tools/w2d_ablate.sh): ND_W2D_DBG names one of the ablation masks / the stamped kernel
+    static const int dbg_env = getenv("ND_W2D_DBG") ? atoi(getenv("ND_W2D_DBG")) : 0;
     switch (dbg_env) {
         case 1: fn = conv_w2d<1>; break;
         case 2: fn = conv_w2d<2>; break;
@@ -575,6 +576,9 @@ int nd_launch_conv_w2d(const ConvDesc &d, hipStream_t stream) {
         case 256: fn = conv_w2d<256>; break;
         default: break;
     }
+#else
+    constexpr int dbg_env = 0;
+#endif
     if (lds_set[dev] != dbg_env + 1) {
         ND_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         lds_set[dev] = dbg_env + 1;
@@ -633,6 +637,7 @@ int nd_launch_conv_w2d(const ConvDesc &d, hipStream_t stream) {
     p.nitems = (int)(first + (ntiles - first) * S);
     p.part = (f32x4 *)d.part;
     const long grid = p.nitems < slots ? p.nitems : slots;
+#ifdef ND_QP_STAMPS
     if (dbg_env == 128) {
         // stamped diagnostic launch: no split-K (p.part carries the stamp buffer), synchronous, prints the phase split per wave role
         static unsigned long long *buf = nullptr;
@@ -667,6 +672,7 @@ int nd_launch_conv_w2d(const ConvDesc &d, hipStream_t stream) {
         }
         return ND_OK;
     }
+#endif
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(512), lds, stream, p);
     if (first < ntiles) hipLaunchKernelGGL(k_w2d_split_finish, dim3((unsigned)(ntiles - first), kMTB * 8), dim3(256), 0, stream, p);
     ND_HIP(hipGetLastError());

@@ -490,21 +490,14 @@ int nd_launch_conv_wino(int T, const ConvDesc &d, void *scratch, size_t scratch_
     const int in_planes = 2 * nd_kblocks(d.cin), out_planes = d.cout / 4;
     const f32x4 *x = (const f32x4 *)d.in.base + (long)d.in_plane0 * d.in.np() + roi_in;
     dim3 gi((unsigned)((g.tiles + 255) / 256), in_planes);
-    static const bool two_pass4 = getenv("ND_WINO_LDS4") != nullptr;   // A/B: the LDS-shared transform kernels for T = 4 too
     // tiles per workgroup of the LDS-shared input transform: 16 (measured on UtNet(64) at cs = 264: 16 and 64 equal on every layer;
-    // 32 is 50 % slower on the 132 x 132 input of tconvs3.0 -- 3.45 against 2.27 ms -- and equal elsewhere); ND_WINO_NTL overrides
-    static const int ntl = getenv("ND_WINO_NTL") ? atoi(getenv("ND_WINO_NTL")) : 16;
-    dim3 gi2((unsigned)((g.tiles + ntl - 1) / ntl), in_planes);
+    // 32 is 50 % slower on the 132 x 132 input of tconvs3.0 -- 3.45 against 2.27 ms -- and equal elsewhere)
+    constexpr int kNtl = 16;
+    dim3 gi2((unsigned)((g.tiles + kNtl - 1) / kNtl), in_planes);
     if (T == 2)
         hipLaunchKernelGGL(k_wino_input<2>, gi, dim3(256), 0, s, x, d.in.np(), d.in.Hb, d.in.Wb, d.in.B, g.TY, g.TX, v, g.vnp, g.vbs);
-    else if (T == 6 && ntl == 16)
-        hipLaunchKernelGGL((k_wino_in2<6, 16>), gi2, dim3(128), 0, s, x, d.in.np(), vHb, vWb, (long)d.in.Hb * d.in.Wb, d.in.Wb, d.in.B, g.TY, g.TX, v, g.vnp, g.vbs);
-    else if (T == 6 && ntl == 64)
-        hipLaunchKernelGGL((k_wino_in2<6, 64>), gi2, dim3(512), 0, s, x, d.in.np(), vHb, vWb, (long)d.in.Hb * d.in.Wb, d.in.Wb, d.in.B, g.TY, g.TX, v, g.vnp, g.vbs);
     else if (T == 6)
-        hipLaunchKernelGGL((k_wino_in2<6, 32>), gi2, dim3(256), 0, s, x, d.in.np(), vHb, vWb, (long)d.in.Hb * d.in.Wb, d.in.Wb, d.in.B, g.TY, g.TX, v, g.vnp, g.vbs);
-    else if (two_pass4)
-        hipLaunchKernelGGL((k_wino_in2<4, 32>), gi2, dim3(192), 0, s, x, d.in.np(), vHb, vWb, (long)d.in.Hb * d.in.Wb, d.in.Wb, d.in.B, g.TY, g.TX, v, g.vnp, g.vbs);
+        hipLaunchKernelGGL((k_wino_in2<6, kNtl>), gi2, dim3(kNtl * 8), 0, s, x, d.in.np(), vHb, vWb, (long)d.in.Hb * d.in.Wb, d.in.Wb, d.in.B, g.TY, g.TX, v, g.vnp, g.vbs);
     else
         hipLaunchKernelGGL(k_wino_input<4>, gi, dim3(256), 0, s, x, d.in.np(), d.in.Hb, d.in.Wb, d.in.B, g.TY, g.TX, v, g.vnp, g.vbs);
     ND_HIP(hipGetLastError());
@@ -562,9 +555,6 @@ int nd_launch_conv_wino(int T, const ConvDesc &d, void *scratch, size_t scratch_
     dim3 go2((unsigned)((g.tiles + 31) / 32), out_planes);
     if (T == 6)
         hipLaunchKernelGGL(k_wino_out2<6>, go2, dim3(256), 0, s, (const f32x4 *)m, g.mnp, g.mbs, d.in.B, g.TY, g.TX, g.Hv, g.Wv, bias,
-                           d.act, d.slope, d.slope_dev, out, d.out.np(), d.out_plane0, (long)d.out.Hb * d.out.Wb, d.out.Wb, d.out.pad, pool, pnp, Hp, Wp, ppad);
-    else if (T == 4 && two_pass4)
-        hipLaunchKernelGGL(k_wino_out2<4>, go2, dim3(192), 0, s, (const f32x4 *)m, g.mnp, g.mbs, d.in.B, g.TY, g.TX, g.Hv, g.Wv, bias,
                            d.act, d.slope, d.slope_dev, out, d.out.np(), d.out_plane0, (long)d.out.Hb * d.out.Wb, d.out.Wb, d.out.pad, pool, pnp, Hp, Wp, ppad);
     else if (T == 2)
         hipLaunchKernelGGL(k_wino_output<2>, go, dim3(128), 0, s, (const f32x4 *)m, g.mnp, g.mbs, d.in.B, g.TY, g.TX, g.Hv, g.Wv, bias,
