@@ -89,7 +89,7 @@ inline bool wino_layer(const LayerSpec &l, int f, int dt) {
 // float offsets of every layer inside the packed blob
 struct BlobLayout {
     size_t off[kNumLayers];
-    size_t woff[kNumLayers];   // Winograd F(4x4,3x3) form of the layer (0: none)
+    size_t woff[kNumLayers];   // three-pass Winograd F(6x6,3x3) form of the layer (0: none)
     size_t w1off[kNumLayers];  // 1-D F(4,3) form fused into the implicit-GEMM kernel (conv_w1d.hip): the other fp32 3x3 layers
     size_t w1off2[kNumLayers]; // ... and its F(2,3) form, for rows whose stage images do not fit the LDS with 18 weight planes
     size_t total;

@@ -1,11 +1,13 @@
-// Winograd F(T x T, 3 x 3) for the wide 3x3 layers (inference, fp32): T = 2 (16 positions, 2.25x fewer MACs) or T = 4 (36 positions,
-// 4x fewer).  Reference op: the Conv2d(3) / ConvTranspose2d(3) layers of networks/UtNet.py:27-88; same math, other association:
+// Winograd F(T x T, 3 x 3) for the wide 3x3 layers (inference, fp32): T = 6 in the network (64 positions, 5.06x fewer MACs than the
+// direct form; V / M are 1.78x the size of X / Y); T = 2 (16 positions, 2.25x) and T = 4 (36 positions, 4x) remain for the layer entry
+// point and the tests.  Reference op: the Conv2d(3) / ConvTranspose2d(3) layers of networks/UtNet.py:27-88; same math, other association:
 //     Y = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A        per (T+2) x (T+2) input tile d -> T x T output tile Y
-// Three passes over HBM, because a fused kernel does not fit the LDS / register budget of one CU (DESIGN.md section 7):
-//   1. k_wino_input   X (quad-planar, bordered)            -> V[pos][Cin/4][tile]   (HBM-bound: reads X once, writes (T+2)^2/T^2 x |X|)
-//   2. conv_qp 1-tap  P = (T+2)^2 independent GEMMs in ONE launch: M[pos] = U[pos] (Cout x Cin) * V[pos]   (MFMA-bound)
-//   3. k_wino_output  M[pos][Cout/4][tile] -> A^T m A + bias, activation -> destination buffer (HBM-bound)
-// It pays where channels are wide: pass 1 + 3 move ~2 (T+2)^2/T^2 x (|X| + |Y|) bytes, pass 2 saves 9 T^2/(T+2)^2 of the MFMAs.
+// Three passes over HBM, because a fused kernel does not fit the LDS / register budget of one CU (DESIGN.md section 4):
+//   1. input transform   X (quad-planar, bordered)         -> V[pos][Cin/4][tile]   (HBM-bound: reads X once, writes (T+2)^2/T^2 x |X|)
+//   2. conv_qp 1-tap     P = (T+2)^2 independent GEMMs in ONE launch: M[pos] = U[pos] (Cout x Cin) * V[pos]   (MFMA-bound)
+//   3. output transform  M[pos][Cout/4][tile] -> A^T m A + bias, activation (+ fused 2x2 max pool) -> destination buffer (HBM-bound)
+// T = 6: k_wino_in2 / k_wino_out2 (a tile shared by 8 threads through LDS); T = 2 | 4: k_wino_input / k_wino_output (one thread per tile).
+// A layer may be restricted to a region of its output (ConvDesc::roi_*: the same passes on shifted base pointers).
 // ConvTranspose2d(3) is the same valid correlation on its zero-bordered input with flipped / transposed weights (as in pack.hip).
 #include <stdlib.h>
 
