@@ -312,7 +312,7 @@ __global__ __launch_bounds__(512) void conv_w2d(ConvParams p) {
         const unsigned offP = (unsigned)((st.img * p.pool_P + (pyp + p.pool_pad) * p.pool_W + pxp + p.pool_pad) * 16);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            f32x4 yy[4];
+            f32x4 yy[4], ypre[4];
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr) {
                 f32x2 m[6];
@@ -331,6 +331,8 @@ __global__ __launch_bounds__(512) void conv_w2d(ConvParams p) {
                 y[3] = b + 8.f * e + m[5];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
+                    ypre[i][2 * pr] = y[i][0];
+                    ypre[i][2 * pr + 1] = y[i][1];
                     if constexpr (decltype(fast)::value) {
                         const f32x2 t = y[i] * slope2;
                         y[i] = f32x2{fmaxf(y[i][0], t[0]), fmaxf(y[i][1], t[1])};
@@ -339,6 +341,16 @@ __global__ __launch_bounds__(512) void conv_w2d(ConvParams p) {
                     }
                     yy[i][2 * pr] = y[i][0];
                     yy[i][2 * pr + 1] = y[i][1];
+                }
+            }
+            if (p.pre) {   // training forward: acc + bias for the activation's backward pass, compact planes [C/4][B][Hv][wpx]
+                const Strip so = strip_of(nb, sl);
+                const int yo = so.y0 + rr, m4 = (q0 + 2 * g + h) * 4, left = p.wpx - so.x0;
+                if (so.ok && yo < p.Hv && m4 < p.M) {
+                    f32x4 *dst = p.pre + (long)(m4 >> 2) * p.pre_plane + ((long)so.img * p.Hv + yo) * p.wpx + so.x0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (i < left) dst[i] = ypre[i];
                 }
             }
             if (DBG & 256) {   // diagnostic: the untransposed stores (each lane its own 4 pixels, 16-byte pieces at a 64-byte stride)
@@ -525,6 +537,11 @@ __global__ __launch_bounds__(256) void k_w2d_split_finish(ConvParams p) {
 }  // namespace
 
 bool nd_w2d_ok(const QpBuf &in) { return in.dt == ND_F32 && in.Hb >= 3 && in.Wb >= 3; }
+// workgroup tiles of a whole layer (16 strips of 8 rows x 4 pixels x 64 output channels each)
+long nd_w2d_tiles(const QpBuf &in, int cout) {
+    const long strips = (long)in.B * ((in.Hb - 2 + kR - 1) / kR) * ((in.Wb - 2 + 3) / 4);
+    return ((strips + kS - 1) / kS) * ((cout + kMTB * 32 - 1) / (kMTB * 32));
+}
 
 // d: the layer as for nd_launch_conv (CONV3 / CONVT3, fp32); d.wpk = nd_w1d_pack blob with T = 4 (the same packing as conv_w1d)
 int nd_launch_conv_w2d(const ConvDesc &d, hipStream_t stream) {
@@ -538,7 +555,7 @@ int nd_launch_conv_w2d(const ConvDesc &d, hipStream_t stream) {
     // (a region is the same launch on shifted base pointers: the kernel knows row / image strides and valid extents separately)
     const int Hv = roi ? d.roi_rows : Hfull, Wpx = roi ? d.roi_cols : Wfull, Wg = (Wpx + 3) / 4, NB = (Hv + kR - 1) / kR;
     const long roi_in = roi ? (long)d.roi_r0 * d.in.Wb + d.roi_c0 : 0, roi_out = roi ? (long)d.roi_r0 * d.out.Wb + d.roi_c0 : 0;
-    if (d.pre) ND_FAIL(ND_EINVAL, "w2d: inference only (no pre-activation copy; the training step uses conv_w1d)");
+    if (d.pre && (d.roi_rows > 0 || d.pool)) ND_FAIL(ND_EINVAL, "w2d: a pre-activation copy goes with whole, unpooled layers only");
     if (d.cout % 4) ND_FAIL(ND_EINVAL, "w2d: cout must be a multiple of 4");
     if (d.in.planes < d.in_plane0 + 2 * KB) ND_FAIL(ND_EINVAL, "w2d: input buffer has %d planes, needs %d", d.in.planes, d.in_plane0 + 2 * KB);
     if (d.out.Hb != Hfull + 2 * d.out.pad || d.out.Wb != Wfull + 2 * d.out.pad || d.out.B != d.in.B) ND_FAIL(ND_EINVAL, "w2d: destination does not fit the result");
@@ -627,8 +644,9 @@ int nd_launch_conv_w2d(const ConvDesc &d, hipStream_t stream) {
     nd_conv_fastdivs(p);
     const long ntiles = p.tiles_per_problem;
     const long slots = cus[dev];
-    // (a layer with a fused pool keeps every tile whole: the split-K finish kernel has no view of a tile's 2x2 neighbours)
-    const long cap = d.part && !d.nosplit && !d.pool ? (long)(d.part_bytes / ((size_t)kMTB * 32 * kSlots * 4)) : 0;
+    // (a layer with a fused pool or a pre-activation copy keeps every tile whole: the split-K finish kernel has no view of a tile's
+    //  2x2 neighbours and writes no copy -- the training step sends layers with few tiles through conv_w1d, which splits)
+    const long cap = d.part && !d.nosplit && !d.pool && !d.pre ? (long)(d.part_bytes / ((size_t)kMTB * 32 * kSlots * 4)) : 0;
     int first, S, cps;
     nd_plan_split(ntiles, KB, slots, cap, &first, &S, &cps);
     p.split_first = first;

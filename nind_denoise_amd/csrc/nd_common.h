@@ -101,6 +101,7 @@ bool nd_w1d_fits(int T, const QpBuf &in);
 int nd_launch_conv_w1d(int T, const ConvDesc &d, hipStream_t stream);
 // the same F(4,3) layer with the input transform shared by the workgroup through LDS (conv_w2d.hip; same packed weights as T = 4)
 bool nd_w2d_ok(const QpBuf &in);
+long nd_w2d_tiles(const QpBuf &in, int cout);   // workgroup tiles of the whole layer
 int nd_launch_conv_w2d(const ConvDesc &d, hipStream_t stream);
 // slack (16-byte elements) behind the last plane of an activation buffer: an N tile of the conv kernels may read a 3x3 halo past
 // the last pixel, a strip of conv_w2d up to 9 rows + 5 pixels

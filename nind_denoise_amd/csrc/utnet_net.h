@@ -429,8 +429,11 @@ int run_stack(int f, int act, int dt, const float *blob, const Plan &pl, hipStre
             const int T = form == FORM_W1D4 ? kW1dTile : 2;
             if (!pre) d.wpk = blob + (T == kW1dTile ? bl.w1off[st.layer] : bl.w1off2[st.layer]);
             d.bias = d.wpk + (size_t)nd_mtiles(ND_CONV3, d.cout) * nd_kblocks(d.cin) * 3 * (T + 2) * 256;
-            if (T == 4 && !pre && !(flags & ND_FLAG_W1D_REGS))
-                ND_TRY(nd_launch_conv_w2d(d, s));     // inference: transform shared through LDS (conv_w2d.hip)
+            // transform shared through LDS (conv_w2d.hip): inference always; training forward (it keeps the pre-activation copy, so its
+            // tiles are never split along K) where the layer has tiles for two rounds of workgroups -- else conv_w1d, which splits
+            const bool w2d_ok = T == 4 && !(flags & ND_FLAG_W1D_REGS) && nd_w2d_ok(d.in) && (!pre || nd_w2d_tiles(d.in, d.cout) >= 512);
+            if (w2d_ok)
+                ND_TRY(nd_launch_conv_w2d(d, s));
             else
                 ND_TRY(nd_launch_conv_w1d(T, d, s));
             continue;

@@ -660,7 +660,11 @@ extern "C" int nd_utnet_train_step(int funit, int flags, const float *params, fl
             d.nosplit = (flags & ND_FLAG_NO_SPLITK) != 0;
             if (bwd_w1[st.layer]) {
                 d.bias = d.wpk + (size_t)nd_mtiles(ND_CONV3, ci) * nd_kblocks(co) * 18 * 256;
-                ND_TRY(nd_launch_conv_w1d(kW1dTile, d, s));
+                // (a data gradient keeps no pre-activation copy: the inference form with the LDS-shared transform applies)
+                if (nd_w2d_ok(d.in) && !(flags & ND_FLAG_W1D_REGS))
+                    ND_TRY(nd_launch_conv_w2d(d, s));
+                else
+                    ND_TRY(nd_launch_conv_w1d(kW1dTile, d, s));
             } else {
                 ND_TRY(nd_launch_conv(d, s));
             }

@@ -1001,6 +1001,34 @@ def test_training_step_gradients_vs_autograd(dev, funit, cs, B, w_l1, w_mse):
     print(f"training step f{funit} cs{cs}: worst relative gradient error {worst:.2e}")
 
 
+def test_training_step_w2d_forward_with_preactivation_copy(dev):
+    # From 512 workgroup tiles up the training forward runs a 3x3 layer through conv_w2d, which then writes the pre-activation copy
+    # itself (9 crops of 184 pixels: 595 tiles on the first level), and every data gradient may take that kernel: the whole step
+    # must agree with the conv_w1d path (flag ND_FLAG_W1D_REGS), which the autograd tests above pin.
+    from nind_denoise_amd.networks.UtNet import UtNet
+    from nind_denoise_amd.train import UtNetTrainer
+    funit, cs, B = 8, 184, 9
+    sd = synth.make_utnet_state_dict(funit=funit, seed=17, gain=1.8)
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(B, 3, cs, cs, generator=g)
+    t = torch.rand(B, 3, cs, cs, generator=g)
+    res = {}
+    for regs in (False, True):
+        net = UtNet(funit=funit)
+        net.load_state_dict(sd)
+        net.w1d_regs = regs
+        tr = UtNetTrainer(net, device=dev, weights={"L1": 0.4, "MSE": 0.6})
+        y, loss = tr.forward_backward(x, t)
+        torch.cuda.synchronize()
+        res[regs] = ({k: tr.grad_of(k).cpu().clone() for k, _ in net.named_parameters()}, y.cpu().clone(), loss.item())
+    assert abs(res[False][2] - res[True][2]) <= 1e-6 * max(1.0, abs(res[True][2]))
+    assert (res[False][1] - res[True][1]).abs().max().item() <= 3e-6
+    for k, ref in res[True][0].items():
+        got = res[False][0][k]
+        assert torch.isfinite(got).all()
+        assert (got - ref).abs().max().item() <= 5e-5 * max(ref.abs().max().item(), 1e-12), k
+
+
 @pytest.mark.parametrize("cs,weights", [(120, {"SSIM": 1.0}), (168, {"MSSSIM": 1.0}),
                                         (184, {"L1": 0.2, "MSE": 0.2, "SSIM": 0.2, "MSSSIM": 0.4})])
 def test_training_step_ssim_losses_vs_autograd(dev, cs, weights):
