@@ -52,7 +52,8 @@ typedef enum nd_dtype {
 } nd_dtype;
 
 /* Per-call arithmetic flags (bit set; 0 = the default path).  There is no process-wide switch: two calls with different
- * flags may run concurrently on different streams. */
+ * flags may run concurrently on different streams, also from different host threads (the launchers' per-device caches -- CU
+ * count, raised dynamic-LDS limits -- are atomics; nd_last_error is thread-local). */
 typedef enum nd_flags {
     ND_FLAG_NO_SPLITK = 1,    /* keep every output tile whole: no split-K tail, so a tile's bits do not depend on which other
                                  tiles share its launch (the default splits the K loop of a launch's last, partial round of

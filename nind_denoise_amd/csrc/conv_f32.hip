@@ -181,7 +181,7 @@ static SplitPlan plan_split(long ntiles, int nchunks, long slots, long max_items
     return b;
 }
 
-static int g_num_cus = 0;
+static std::atomic<int> g_num_cus{0};   // CU count of the device in use (every GPU of a node is the same part)
 static const double kSplitOver = 3.0;
 
 // max_items = 0 (no scratch, or ND_FLAG_NO_SPLITK on the call): never split
@@ -212,7 +212,7 @@ static int pick_variant(const ConvDesc &d, int M) {
             // against the CU count, so compare whole rounds.
             int Hv, Wv, st_;
             valid_grid(9, d.in, &Hv, &Wv, &st_);
-            const int cus = g_num_cus > 0 ? g_num_cus : 256;
+            const int cus = g_num_cus.load(std::memory_order_relaxed) > 0 ? g_num_cus.load(std::memory_order_relaxed) : 256;
             double best = 0;
             int best_v = -1;
             // (16-bit storage: the MFMAs are 16x faster, the LDS-DMA stream per CU is the bound -> the 128 x 512 tile, 35 KB of DMA
@@ -269,7 +269,7 @@ bool nd_conv_roi_fits(const ConvDesc &d) {
     return variant_lds(variant_at(v), d.in, nullptr, nullptr, d.roi_rows > 0 ? d.roi_rows : 0, d.roi_rows > 0 ? d.roi_cols : 0) <= kMaxLds;
 }
 
-static int g_lds_set[16][64] = {{0}};   // per device: function attributes belong to the device's copy of the code object
+static std::atomic<int> g_lds_set[16][64];   // per device: function attributes belong to the device's copy of the code object
 
 int nd_launch_conv(const ConvDesc &d, hipStream_t stream) {
     const int taps = nd_taps(d.kind);
@@ -283,13 +283,11 @@ int nd_launch_conv(const ConvDesc &d, hipStream_t stream) {
     const long NP = d.in.used();
     if (NP >= (1L << 31)) ND_FAIL(ND_EINVAL, "conv: %ld linear pixels exceed the int32 index range", NP);
 
-    if (!g_num_cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        ND_HIP(hipGetDevice(&dev));
-        ND_HIP(hipGetDeviceProperties(&prop, dev));
-        g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    int dev = 0, ncus = 0;
+    ND_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) ND_FAIL(ND_EINVAL, "conv: device index %d", dev);
+    ND_TRY(nd_num_cus(dev, &ncus));
+    g_num_cus.store(ncus, std::memory_order_relaxed);
     int v = d.variant >= 0 ? d.variant : pick_variant(d, M);
     if (v < 0 || v >= g_nvariants) ND_FAIL(ND_EINVAL, "conv: unknown variant %d", v);
     const Variant &V = variant_at(v);
@@ -346,19 +344,9 @@ int nd_launch_conv(const ConvDesc &d, hipStream_t stream) {
     bool cross = true;
     const size_t lds = variant_lds(V, d.in, &cross, &p.G, roi ? p.Hv : 0, roi ? p.Wv : 0);
     if (lds > kMaxLds) ND_FAIL(ND_EINVAL, "conv: %zu B of LDS needed (row width %d too large for variant %s)", lds, p.Wb, V.name);
-    int dev = 0;
-    ND_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 16) ND_FAIL(ND_EINVAL, "conv: device index %d", dev);
-    if ((int)lds > g_lds_set[dev][v]) {
+    if ((int)lds > g_lds_set[dev][v].load(std::memory_order_relaxed)) {
         ND_HIP(hipFuncSetAttribute((const void *)V.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        g_lds_set[dev][v] = (int)lds;
-    }
-    if (!g_num_cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        ND_HIP(hipGetDevice(&dev));
-        ND_HIP(hipGetDeviceProperties(&prop, dev));
-        g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        g_lds_set[dev][v].store((int)lds, std::memory_order_relaxed);
     }
 
     if (cross) {
@@ -381,7 +369,7 @@ int nd_launch_conv(const ConvDesc &d, hipStream_t stream) {
     nd_conv_fastdivs(p);
     const long ntiles = (long)p.tiles_per_problem * (d.nbatch > 1 ? d.nbatch : 1);
     const int per_cu = lds * 2 <= kMaxLds && V.threads <= 256 ? 2 : 1;
-    const long slots = (long)g_num_cus * per_cu;
+    const long slots = (long)ncus * per_cu;
     const long cap = d.part && !d.nosplit ? (long)(d.part_bytes / ((size_t)V.mblk * V.nblk * 4)) : 0;
     const SplitPlan sp = plan_split(ntiles, KB / V.kbc, slots, cap, kSplitOver);
     p.split_first = sp.first;

@@ -414,23 +414,19 @@ int nd_launch_conv_w1d(int T, const ConvDesc &d, hipStream_t stream) {
     if (d.out_plane0 + d.cout / 4 > d.out.planes) ND_FAIL(ND_EINVAL, "w1d: destination planes overflow");
     if (d.in.used() >= (1L << 31)) ND_FAIL(ND_EINVAL, "w1d: input too large for int32 indexing");
 
-    static int cus[16] = {0}, lds_set[16][2] = {{0}};
-    int dev = 0;
+    static std::atomic<int> lds_set[16][2];
+    int dev = 0, ncus = 0;
     ND_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 16) ND_FAIL(ND_EINVAL, "w1d: device index %d", dev);
-    if (!cus[dev]) {
-        hipDeviceProp_t prop;
-        ND_HIP(hipGetDeviceProperties(&prop, dev));
-        cus[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    ND_TRY(nd_num_cus(dev, &ncus));
     bool cross;
     size_t lds;
     const int G = w1d_geometry(sh, d.in, &cross, &lds);
     if (lds > 160 * 1024) ND_FAIL(ND_EINVAL, "w1d: %zu B of LDS needed (row width %d too large)", lds, d.in.Wb);
     void (*fn)(ConvParams) = T == 4 ? conv_w1d<4, 1, 2, 4, kW1dStages> : conv_w1d<2, 2, 1, 8, kW1dStages>;
-    if ((int)lds > lds_set[dev][T == 4]) {
+    if ((int)lds > lds_set[dev][T == 4].load(std::memory_order_relaxed)) {
         ND_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set[dev][T == 4] = (int)lds;
+        lds_set[dev][T == 4].store((int)lds, std::memory_order_relaxed);
     }
 
     ConvParams p = {};
@@ -472,7 +468,7 @@ int nd_launch_conv_w1d(int T, const ConvDesc &d, hipStream_t stream) {
     p.n_tiles_m = (d.cout + sh.mblk - 1) / sh.mblk;
     p.tiles_per_problem = p.n_tiles_n * p.n_tiles_m;
     const long ntiles = p.tiles_per_problem;
-    const long slots = cus[dev];
+    const long slots = ncus;
     const long cap = d.part && !d.nosplit ? (long)(d.part_bytes / ((size_t)sh.mblk * T * sh.groups * 4)) : 0;
     int first, S, cps;
     nd_plan_split(ntiles, KB, slots, cap, &first, &S, &cps);

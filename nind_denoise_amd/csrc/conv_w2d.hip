@@ -564,15 +564,11 @@ int nd_launch_conv_w2d(const ConvDesc &d, hipStream_t stream) {
     // pixels past the last valid pixel (the buffers carry that slack)
     if (2 * d.in.np() * 16 + 65536 >= (1L << 32) || d.in.used() >= (1L << 31)) ND_FAIL(ND_EINVAL, "w2d: input too large for 32-bit byte offsets");
 
-    static int cus[16] = {0}, lds_set[16] = {0};
-    int dev = 0;
+    static std::atomic<int> lds_set[16];
+    int dev = 0, ncus = 0;
     ND_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 16) ND_FAIL(ND_EINVAL, "w2d: device index %d", dev);
-    if (!cus[dev]) {
-        hipDeviceProp_t prop;
-        ND_HIP(hipGetDeviceProperties(&prop, dev));
-        cus[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    ND_TRY(nd_num_cus(dev, &ncus));
     const int lds = kLds;
     void (*fn)(ConvParams) = conv_w2d<0>;
 #ifdef ND_QP_STAMPS
@@ -596,9 +592,9 @@ int nd_launch_conv_w2d(const ConvDesc &d, hipStream_t stream) {
 #else
     constexpr int dbg_env = 0;
 #endif
-    if (lds_set[dev] != dbg_env + 1) {
+    if (lds_set[dev].load(std::memory_order_relaxed) != dbg_env + 1) {
         ND_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        lds_set[dev] = dbg_env + 1;
+        lds_set[dev].store(dbg_env + 1, std::memory_order_relaxed);
     }
 
     ConvParams p = {};
@@ -643,7 +639,7 @@ int nd_launch_conv_w2d(const ConvDesc &d, hipStream_t stream) {
     p.tiles_per_problem = p.n_tiles_n * p.n_tiles_m;
     nd_conv_fastdivs(p);
     const long ntiles = p.tiles_per_problem;
-    const long slots = cus[dev];
+    const long slots = ncus;
     // (a layer with a fused pool or a pre-activation copy keeps every tile whole: the split-K finish kernel has no view of a tile's
     //  2x2 neighbours and writes no copy -- the training step sends layers with few tiles through conv_w1d, which splits)
     const long cap = d.part && !d.nosplit && !d.pool && !d.pre ? (long)(d.part_bytes / ((size_t)kMTB * 32 * kSlots * 4)) : 0;

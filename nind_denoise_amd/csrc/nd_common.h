@@ -1,6 +1,8 @@
 // Internal declarations shared by the translation units of libnind_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -106,6 +108,26 @@ int nd_launch_conv_w2d(const ConvDesc &d, hipStream_t stream);
 // slack (16-byte elements) behind the last plane of an activation buffer: an N tile of the conv kernels may read a 3x3 halo past
 // the last pixel, a strip of conv_w2d up to 9 rows + 5 pixels
 static inline size_t nd_buf_slack(int Wb) { return (size_t)10 * Wb + 8 + 2048; }
+// Per-device launch caches (CU count, "dynamic LDS size already raised for this kernel") are std::atomic: entry points may be
+// called from several host threads (include/nind_hip.h), and two threads that both miss write the same value.
+// CU count of device `dev` (0 <= dev < 16), queried once per device.
+static inline int nd_num_cus(int dev, int *out) {
+    static std::atomic<int> cus[16];
+    int n = cus[dev].load(std::memory_order_relaxed);
+    if (!n) {
+        hipDeviceProp_t prop;
+        ND_HIP(hipGetDeviceProperties(&prop, dev));
+        n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        cus[dev].store(n, std::memory_order_relaxed);
+    }
+    *out = n;
+    return ND_OK;
+}
+// the arithmetic switches every flags-taking entry point accepts (include/nind_hip.h: nd_flags); unknown bits are an error
+static inline int nd_check_flags(int flags) {
+    if (flags & ~(ND_FLAG_NO_SPLITK | ND_FLAG_DIRECT_CONV | ND_FLAG_W1D_REGS | ND_FLAG_FULL_TILES)) ND_FAIL(ND_EINVAL, "unknown flag bits 0x%x", flags);
+    return ND_OK;
+}
 const char *nd_conv_variant_label(int v);
 
 // packed size helpers (host)

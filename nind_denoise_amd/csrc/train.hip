@@ -60,7 +60,7 @@ QpBuf make_buf(char *base, size_t *off, int planes, int B, int H, int W) {
     q.pstride = (long)B * H * W;
     q.dt = ND_F32;
     q.base = (float *)(base ? base + *off : nullptr);
-    *off += ((size_t)planes * q.pstride + 2 * W + 2 + 2048) * 16;
+    *off += ((size_t)planes * q.pstride + nd_buf_slack(W)) * 16;
     *off = (*off + 255) & ~(size_t)255;
     return q;
 }

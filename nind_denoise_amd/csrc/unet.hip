@@ -103,7 +103,7 @@ UPlan make_plan(int h, int w, int B, char *base) {
         q.pad = pad;
         q.pstride = (long)B * q.Hb * q.Wb;
         q.base = (float *)(base + off);
-        off += ((size_t)q.planes * q.pstride + 2 * q.Wb + 2 + 2048) * 16;
+        off += ((size_t)q.planes * q.pstride + nd_buf_slack(q.Wb)) * 16;
         off = (off + 255) & ~(size_t)255;
     };
     add(XIN, 8, 0, 1); add(I1, 64, 0, 1); add(CAT4, 128, 0, 1);

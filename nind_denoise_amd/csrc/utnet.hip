@@ -134,10 +134,6 @@ static int forward_common(int funit, int act, int dtype, const void *packed, int
     return ND_OK;
 }
 
-static int check_flags(int flags) {
-    if (flags & ~(ND_FLAG_NO_SPLITK | ND_FLAG_DIRECT_CONV | ND_FLAG_W1D_REGS | ND_FLAG_FULL_TILES)) ND_FAIL(ND_EINVAL, "unknown flag bits 0x%x", flags);
-    return ND_OK;
-}
 extern "C" int nd_utnet_forward_hw(int funit, int act, int dtype, int flags, const void *packed, const float *x, float *y,
                                    int batch, int h, int w, void *ws, size_t ws_bytes, void *stream);
 extern "C" int nd_utnet_forward(int funit, int act, int dtype, int flags, const void *packed, const float *x, float *y,
@@ -146,7 +142,7 @@ extern "C" int nd_utnet_forward(int funit, int act, int dtype, int flags, const 
 }
 extern "C" int nd_utnet_forward_hw(int funit, int act, int dtype, int flags, const void *packed, const float *x, float *y,
                                    int batch, int h, int w, void *ws, size_t ws_bytes, void *stream) {
-    ND_TRY(check_flags(flags));
+    ND_TRY(nd_check_flags(flags));
     Plan pl;
     ND_TRY(forward_common(funit, act, dtype, packed, batch, batch, h, w, ws, ws_bytes, &pl));
     if (!x || !y) ND_FAIL(ND_EINVAL, "UtNet: null tensor");
@@ -163,7 +159,7 @@ extern "C" int nd_utnet_forward_hw(int funit, int act, int dtype, int flags, con
 extern "C" int nd_utnet_denoise_tiles(int funit, int act, int dtype, int flags, const void *packed, const float *img,
                                       float *canvas, int width, int height, int cs, int ucs, int ol, int tile_begin,
                                       int tile_count, int batch, void *ws, size_t ws_bytes, void *stream) {
-    ND_TRY(check_flags(flags));
+    ND_TRY(nd_check_flags(flags));
     Plan pl;
     ND_TRY(forward_common(funit, act, dtype, packed, batch, tile_count, cs, cs, ws, ws_bytes, &pl));
     if (!img || !canvas) ND_FAIL(ND_EINVAL, "UtNet: null image");
@@ -190,18 +186,23 @@ extern "C" int nd_utnet_denoise_tiles(int funit, int act, int dtype, int flags, 
 // padding-zero MACs); `mfma_flops` = what the matrix cores execute in the form the layer ran in (MFMAs issued x 4096).
 extern "C" int nd_utnet_profile_stack(int funit, int act, int dtype, int flags, const void *packed, int batch, int cs, int crop,
                                       void *ws, size_t ws_bytes, void *stream, nd_step_profile *steps, int max_steps) {
-    ND_TRY(check_flags(flags));
+    ND_TRY(nd_check_flags(flags));
     Plan pl;
     ND_TRY(forward_common(funit, act, dtype, packed, batch, batch, cs, cs, ws, ws_bytes, &pl));
     if (max_steps < kNumSteps || !steps) ND_FAIL(ND_EINVAL, "nd_utnet_profile_stack: need room for %d steps", kNumSteps);
+    if (crop < 0 || 2 * crop >= cs) ND_FAIL(ND_EINVAL, "nd_utnet_profile_stack: crop %d", crop);
     hipStream_t s = (hipStream_t)stream;
-    hipEvent_t ev[kNumSteps + 1], evx[2 * kNumSteps];
-    for (auto &e : ev) ND_HIP(hipEventCreate(&e));
-    for (auto &e : evx) ND_HIP(hipEventCreate(&e));
+    // every argument is validated above: from here on the events are destroyed on every exit path
+    struct Events {
+        hipEvent_t ev[kNumSteps + 1 + 2 * kNumSteps];
+        int n = 0;
+        ~Events() { for (int i = 0; i < n; ++i) (void)hipEventDestroy(ev[i]); }
+    } evs;
+    for (; evs.n < kNumSteps + 1 + 2 * kNumSteps; ++evs.n) ND_HIP(hipEventCreate(&evs.ev[evs.n]));
+    hipEvent_t *const ev = evs.ev, *const evx = evs.ev + kNumSteps + 1;
     const BlobLayout bl = blob_layout(funit, dtype);
     Roi rois[kNumSteps];
     const Roi *use = nullptr;
-    if (crop < 0 || 2 * crop >= cs) ND_FAIL(ND_EINVAL, "nd_utnet_profile_stack: crop %d", crop);
     if (!(flags & ND_FLAG_FULL_TILES) && plan_rois(pl, crop, crop, rois) && rois_supported(funit, dtype, flags, pl, bl, rois)) use = rois;
     int rc = run_stack(funit, act, dtype, (const float *)packed, pl, s, flags, ev, nullptr, nullptr, nullptr, evx, use);
     if (rc == ND_OK) {
@@ -274,8 +275,6 @@ extern "C" int nd_utnet_profile_stack(int funit, int act, int dtype, int flags, 
             nd_wino_xform_bytes(kWinoTile, v, (int)ci, (int)co, &o.xform_bytes_in, &o.xform_bytes_out);
         }
     }
-    for (auto &e : ev) (void)hipEventDestroy(e);
-    for (auto &e : evx) (void)hipEventDestroy(e);
     return rc;
 }
 
@@ -381,7 +380,7 @@ extern "C" size_t nd_layer_workspace_bytes(int kind, int batch, int cin, int cou
 extern "C" int nd_layer_forward(int kind, int act, float slope, int dtype, const void *packed, const float *x, int batch,
                                 int cin, int h, int w, int cout, float *y, void *ws, size_t ws_bytes, int variant, int flags,
                                 void *stream) {
-    ND_TRY(check_flags(flags));
+    ND_TRY(nd_check_flags(flags));
     if (dtype < ND_F32 || dtype > ND_F16) ND_FAIL(ND_EINVAL, "nd_layer_forward: unsupported dtype %d", dtype);
     const size_t need = nd_layer_workspace_bytes(kind, batch, cin, cout, h, w, dtype);
     if (!need) ND_FAIL(ND_EINVAL, "nd_layer_forward: bad shape");
@@ -440,7 +439,7 @@ extern "C" size_t nd_layer_winograd_workspace_bytes(int tile, int kind, int batc
 extern "C" int nd_layer_forward_winograd(int tile, int kind, int act, float slope, const void *packed, const float *x, int batch,
                                          int cin, int h, int w, int cout, float *y, void *ws, size_t ws_bytes, int flags,
                                          void *stream) {
-    ND_TRY(check_flags(flags));
+    ND_TRY(nd_check_flags(flags));
     const size_t need = nd_layer_winograd_workspace_bytes(tile, kind, batch, cin, cout, h, w);
     if (!need) ND_FAIL(ND_EINVAL, "nd_layer_forward_winograd: bad shape / kind / tile");
     if (!ws || ws_bytes < need) ND_FAIL(ND_ENOMEM, "nd_layer_forward_winograd: workspace %zu B given, %zu B needed", ws_bytes, need);

@@ -347,7 +347,7 @@ TrainPlan make_train_plan(int f, int cs, int B, char *base) {
         q.dt = ND_F32;
         q.pstride = (long)B * Hb * Wb;
         q.base = (float *)(base ? base + off : nullptr);
-        off += ((size_t)planes * q.pstride + 2 * Wb + 2 + 2048) * 16;
+        off += ((size_t)planes * q.pstride + nd_buf_slack(Wb)) * 16;
         off = (off + 255) & ~(size_t)255;
     };
     // pre-activation copies: compact, the layer's output size
@@ -470,6 +470,7 @@ extern "C" int nd_utnet_train_workspace_init(void *ws, size_t ws_bytes, int funi
 extern "C" int nd_utnet_train_step(int funit, int flags, const float *params, float *grads, void *blobs, const float *x,
                                    const float *target, float *y_out, float w_l1, float w_mse, float w_ssim, float w_msssim,
                                    float *loss_out, int batch, int cs, int loss_cs, void *ws, size_t ws_bytes, void *stream) {
+    ND_TRY(nd_check_flags(flags));
     ND_TRY(check_train(funit, cs, batch));
     const int L = loss_cs > 0 ? loss_cs : cs;   // the criteria see the centre crop of this size (nn_train.py:319-323)
     if (L > cs) ND_FAIL(ND_EINVAL, "UtNet training: loss_cs=%d exceeds the crop size %d", L, cs);

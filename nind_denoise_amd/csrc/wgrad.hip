@@ -237,14 +237,14 @@ int nd_launch_wgrad(const QpBuf &A, int a_plane0, int M, const QpBuf &Bq, int b_
     p.nblk = p.Np / 64;
     const int lds = 2 * ((16 + (taps == 9 ? 3 : 1) * 16) * (1024 + 16));
     dim3 grid((p.Mp / 64) * p.nblk, ksplit);
-    static bool lds_set[16][2] = {{false}};   // per device: function attributes belong to the device's copy of the code object
+    static std::atomic<bool> lds_set[16][2];   // per device: function attributes belong to the device's copy of the code object
     int dev = 0;
     ND_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 16) ND_FAIL(ND_EINVAL, "wgrad: device index %d", dev);
-    if (!lds_set[dev][taps == 9]) {
+    if (!lds_set[dev][taps == 9].load(std::memory_order_relaxed)) {
         const void *fn = taps == 9 ? (const void *)k_wgrad<9> : (const void *)k_wgrad<1>;
         ND_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        lds_set[dev][taps == 9] = true;
+        lds_set[dev][taps == 9].store(true, std::memory_order_relaxed);
     }
     if (taps == 9)
         hipLaunchKernelGGL(k_wgrad<9>, grid, dim3(768), lds, s, p);

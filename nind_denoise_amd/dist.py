@@ -10,6 +10,10 @@ denoise_image.py:240-267 is partitioned into contiguous tile-index shards, one p
                shard seam receives contributions from two ranks, so its fp32 sum is re-associated with respect to the
                single-GPU tile order (<= 1 ulp); everything else is bit-identical to one GPU.
 
+A STREAM of frames runs the same partition software-pipelined (`ShardedFrameStream`): the scatter of frame n+1 and the gather +
+band adds of frame n-1 travel on a side stream under the compute of frame n, so the per-frame cost at N ranks is the compute
+of the largest shard, not compute + two exchanges.
+
 The exchange logic is backend-agnostic (tests run it on gloo/CPU with world_size 2).
 """
 import torch
@@ -144,6 +148,136 @@ def denoise_frame_sharded(compute, frame, canvas, geo, group=None, root=0):
     return canvas
 
 
+class ShardedFrameStream:
+    """Tile-shard of a STREAM of equally sized frames over the ranks of `group`, software-pipelined across frames.
+
+    The partition is `denoise_frame_sharded`'s (contiguous tile-index shards of the loop of denoise_image.py:240-267; frames
+    enter and leave through `root`).  Step n of the pipeline overlaps, on every rank,
+
+        K(n)   crop -> UtNet -> stitch of this rank's shard of frame n                      (caller's stream)
+        C(n)   ONE grouped point-to-point batch: root -> peers the input row bands of frame n+1,
+               peers -> root the canvas row bands of frame n-1; then root adds those bands       (side stream)
+
+    over rings of two frame / canvas / landing buffers per rank (whole [3,H,W] buffers: a band is received straight into its
+    rows, per channel, so nothing is repacked; 288 MB each at 24 MP -- HBM is not the constraint).  K(n) is enqueued before C(n)
+    is issued, C(n) waits for K(n-1) only, K(n+1) waits for C(n): in steady state a frame costs max(compute of the largest
+    shard, exchange) instead of their sum, and the pipeline holds a frame for two extra steps.  Both sides issue the scatter and
+    the gather of a step in one batch_isend_irecv group, so no send can wait behind an unmatched receive.
+
+    compute(frame, canvas, lo, hi) adds the contributions of tiles [lo, hi) to `canvas` (pipeline.denoise_frame with tile_range /
+    canvas does).  On a gloo group with CUDA tensors (the one-GPU rehearsal) messages are staged through host memory; the
+    schedule is the same.  With CPU tensors (tests with the oracle as compute) everything is synchronous.
+    """
+
+    def __init__(self, compute, geo, device, group=None, root=0):
+        self.compute, self.geo, self.group, self.root = compute, geo, group, root
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.staged = self.cuda and _host_staged(group)
+        self.lo, self.hi = geo.shard(self.rank, self.world)
+        self.bands_in = [geo.rows_in(*geo.shard(r, self.world)) for r in range(self.world)]
+        self.bands_out = [geo.rows_out(*geo.shard(r, self.world)) for r in range(self.world)]
+        shape = (3, geo.H, geo.W)
+        self.is_root = self.rank == root
+        self.canvas = [torch.zeros(shape, dtype=torch.float32, device=self.device) for _ in range(2)]
+        self.frames = None if self.is_root else [torch.zeros(shape, dtype=torch.float32, device=self.device) for _ in range(2)]
+        self.land = None
+        if self.is_root:
+            self.land = [{r: torch.empty((3, b - a, geo.W), dtype=torch.float32, device=self.device)
+                          for r, (a, b) in enumerate(self.bands_out) if r != root and b > a} for _ in range(2)]
+        if self.cuda:
+            with torch.cuda.device(self.device):
+                self.s_comm = torch.cuda.Stream()
+                self.ev_k = [torch.cuda.Event() for _ in range(2)]
+                self.ev_c = torch.cuda.Event()
+                self.ev_ready = torch.cuda.Event()
+
+    # -- one exchange step: scatter of frame n+1 (if any), gather + adds of frame n-1 (if any)
+    def _exchange(self, n, n_frames, src_next):
+        geo, root = self.geo, self.root
+        do_scatter, do_gather = n + 1 < n_frames, n - 1 >= 0
+        ops, after = [], []
+        if self.is_root:
+            if do_scatter:
+                for r, (a, b) in enumerate(self.bands_in):
+                    if r != root and b > a:
+                        for c in range(3):
+                            ops.append((dist.isend, src_next[c, a:b, :], r))
+            if do_gather:
+                slot = (n - 1) % 2
+                for r, buf in self.land[slot].items():
+                    a, b = self.bands_out[r]
+                    for c in range(3):
+                        ops.append((dist.irecv, buf[c], r))
+                    after.append((self.canvas[slot], a, b, buf))
+        else:
+            a, b = self.bands_in[self.rank]
+            if do_scatter and b > a:
+                for c in range(3):
+                    ops.append((dist.irecv, self.frames[(n + 1) % 2][c, a:b, :], root))
+            a, b = self.bands_out[self.rank]
+            if do_gather and b > a:
+                for c in range(3):
+                    ops.append((dist.isend, self.canvas[(n - 1) % 2][c, a:b, :], root))
+        if self.staged:
+            # gloo moves host memory: device -> host for what is sent, host -> device for what arrived (on the side stream)
+            host = [(fn, t.cpu() if fn is dist.isend else torch.empty(t.shape, dtype=t.dtype), peer, t) for fn, t, peer in ops]
+            _p2p([dist.P2POp(fn, h, peer, self.group) for fn, h, peer, _ in host], self.group)
+            for fn, h, _, t in host:
+                if fn is dist.irecv:
+                    t.copy_(h, non_blocking=False)
+        else:
+            _p2p([dist.P2POp(fn, t, peer, self.group) for fn, t, peer in ops], self.group)
+        for cv, a, b, buf in after:      # bands added in rank order (deterministic)
+            cv[:, a:b, :] += buf
+
+    def run(self, frames, n_frames):
+        """Generator.  `frames`: iterable of [3,H,W] tensors on `root` (ignored elsewhere); every rank passes the same `n_frames`.
+        Yields (index, canvas) on root as frames complete, in order -- the canvas is a ring slot, valid until two more frames
+        have been taken from the generator; yields (index, None) on the other ranks."""
+        geo = self.geo
+        it = iter(frames) if self.is_root else None
+
+        def take():
+            f = next(it)
+            if tuple(f.shape) != (3, geo.H, geo.W):
+                raise ValueError(f"ShardedFrameStream: frame shape {tuple(f.shape)} != {(3, geo.H, geo.W)}")
+            return f
+
+        cur_src = take() if (self.is_root and n_frames > 0) else None
+        for n in range(-1, n_frames + 1):
+            nxt_src = take() if (self.is_root and n + 1 < n_frames and n >= 0) else (cur_src if n == -1 else None)
+            if self.cuda:
+                cur = torch.cuda.current_stream(self.device)
+                self.ev_ready.record(cur)          # the caller's frames are ready at this point of its stream
+            if 0 <= n < n_frames:
+                slot = n % 2
+                cv = self.canvas[slot]
+                a, b = self.bands_out[self.rank]
+                if self.is_root:
+                    cv.zero_()
+                elif b > a:
+                    cv[:, a:b, :].zero_()
+                self.compute(cur_src if self.is_root else self.frames[slot], cv, self.lo, self.hi)
+                if self.cuda:
+                    self.ev_k[slot].record(cur)
+            if self.cuda:
+                with torch.cuda.stream(self.s_comm):
+                    self.s_comm.wait_event(self.ev_ready)
+                    if n - 1 >= 0:
+                        self.s_comm.wait_event(self.ev_k[(n - 1) % 2])
+                    self._exchange(n, n_frames, nxt_src)
+                    self.ev_c.record(self.s_comm)
+                cur.wait_event(self.ev_c)          # K(n+1) needs the bands of C(n); the canvas of frame n-1 is complete behind it
+            else:
+                self._exchange(n, n_frames, nxt_src)
+            if n >= 1:
+                yield n - 1, (self.canvas[(n - 1) % 2] if self.is_root else None)
+            if n >= 0:
+                cur_src = nxt_src
+
+
 def frame_shard(n_frames, rank, world):
     """Frame-level sharding of a multi-frame batch (BASELINE configs[2]: 100 frames over 8 GPUs): frame f goes to rank
     f % world.  Whole frames are independent, so there is no per-frame exchange at all -- only the one-time weight broadcast."""
@@ -153,27 +287,37 @@ def frame_shard(n_frames, rank, world):
 def denoise_frames_sharded(denoise, frames, group=None, collect=True):
     """A batch of frames across the ranks of `group`, frame-level sharding.
 
-    frames: list of [3,H,W] tensors (every rank holds, or can produce, the frames it owns: only frames[f] with
-    f % world == rank are touched).  denoise(frame) -> stitched canvas (pipeline.denoise_frame / serve.FrameEngine).
+    frames: list of equally shaped [3,H,W] tensors (checked).  Every rank holds, or can produce, the frames it owns: only the
+    CONTENT of frames[f] with f % world == rank is read; of the others only the shape (rank 0 sizes its landing buffers from it).
+    denoise(frame) -> stitched canvas (pipeline.denoise_frame / serve.FrameEngine).
     Returns {frame index: canvas} for the frames this rank owns; with collect=True rank 0 receives every other rank's
     canvases too (point-to-point, one message per frame) and returns the full dict -- the serving case, where results
     leave through one process."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    shapes = {tuple(f.shape) for f in frames}
+    if len(shapes) > 1:
+        # the landing buffers on rank 0 are sized from frames[f].shape, which every rank must therefore know and agree on
+        raise ValueError(f"denoise_frames_sharded: all frames of a batch must have one shape, got {sorted(shapes)}")
     mine = frame_shard(len(frames), rank, world)
     out = {f: denoise(frames[f]) for f in mine}
     if not collect or world == 1:
         return out
     if rank == 0:
+        # every receive posted in ONE batch (the peers send in frame order); only the SHAPE of a foreign frame is looked at
+        like = out[mine[0]] if mine else None
+        ops, bufs = [], {}
         for f in range(len(frames)):
             src = f % world
             if src != 0:
-                like = out[mine[0]] if mine else frames[f]
-                buf = _landing(tuple(like.shape), like, group)
-                _p2p([dist.P2POp(dist.irecv, buf, src, group)], group)
-                out[f] = buf.to(like.device)
+                ref = like if like is not None else frames[f]
+                bufs[f] = _landing(tuple(frames[f].shape), ref, group)
+                ops.append(dist.P2POp(dist.irecv, bufs[f], src, group))
+        _p2p(ops, group)
+        for f, buf in bufs.items():
+            out[f] = buf.to(like.device) if like is not None else buf
     else:
-        for f in mine:
-            _p2p([dist.P2POp(dist.isend, _wire(out[f], group), 0, group)], group)
+        wires = [_wire(out[f], group) for f in mine]
+        _p2p([dist.P2POp(dist.isend, w, 0, group) for w in wires], group)
     return out
 
 
