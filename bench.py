@@ -6,14 +6,19 @@
 
 A "step" is one 6000x4000 frame through the device-resident crop -> UtNet -> stitch loop (BASELINE.json configs[1],
 geometry "G24" of SURVEY.md section 8: cs=264 is the valid tile size nearest to the named 256, which the reference
-network itself rejects).  The frame is resident in HBM when the timed region starts and the stitched canvas is in HBM when
-it ends.  With N > 1 the path shards by FRAME (frames are independent; no data-path collective): a step is N frames, one per
-rank, every rank runs the whole loop on its own frame -> per-GPU work is fixed as N grows, "scaling": "weak", value = all
-ranks' megapixels / max-over-ranks time.  `--frames F` fixes the step at F frames dealt round-robin to the ranks (BASELINE
-configs[2]'s shape; "strong" over the batch).  `--tile-shard` is the single-frame latency mode: the tile index range of ONE
-frame is split into N contiguous shards; inside the timed region rank 0 sends every rank the image rows its shard reads (RCCL
-point-to-point over xGMI), every rank denoises its shard into its own canvas and rank 0 receives and adds the canvas row bands
-(nind_denoise_amd/dist.py): total work per step is fixed -> "strong".
+network itself rejects).  The frame is resident in HBM (on rank 0) when the timed region starts and the stitched canvas is in
+HBM (on rank 0) when it ends.
+
+N > 1 (default): north_star's partition -- the TILE loop of every frame is sharded over the ranks (contiguous tile-index
+shards, denoise_image.py:240-267).  Rank 0 owns the model and the frames: it broadcasts the raw parameters once (124 MB; every
+rank packs them into MFMA fragment order on its own device), and per frame sends each rank the image rows its shard reads and
+receives + adds the canvas rows it wrote (RCCL point-to-point over xGMI).  The stream of frames is software-pipelined
+(nind_denoise_amd/dist.py: ShardedFrameStream): the scatter of frame n+1 and the gather of frame n-1 run on a side stream under
+the compute of frame n.  Total work per step is fixed as N grows -> "scaling": "strong"; `value` = megapixels of the frames that
+left rank 0 / max-over-ranks time.  The same line carries, under `frame_shard`, the rate of N independent REPLICAS (one whole
+frame per rank per step, no data-path traffic) -- labelled as such, not the metric.
+`--frames F` times BASELINE configs[2]'s shape instead (a step = F frames dealt round-robin to the ranks, no per-frame exchange);
+`--frame-per-rank` makes the replicas mode the timed one.
 
 The timed loop is the product's default: every tile's whole cs x cs crop goes in, every layer runs, and the layers of the last
 decoder levels compute only the outputs that the tile's useful centre (what the stitch keeps) depends on; `--whole-tiles` times
@@ -25,13 +30,19 @@ One JSON line on rank 0:
                 FLOP / HIP-event time on the launch stream / MFMA peak (<= 1 by construction); the algorithmic
                 (direct-convolution) rate is reported beside it, and `families` prices every kernel family against its own
                 bound (transform passes against HBM)
-  parity        max |HIP - oracle| over the tiles the cpu_baseline leg pushes through the oracle anyway
+  parity        the TIMED path (pipeline.denoise_frame: fused gather -> useful-region conv stack -> stitch, whole launches of
+                `batch` tiles) against the oracle's stitched canvas of the tiles the cpu_baseline leg computes anyway
   cpu_baseline  the oracle (torch CPU fp32, the primitives the reference runs) on a bounded sample of the same frame's tiles,
                 in grad mode (as the reference runs, denoise_image.py:246) and under no_grad
+  other_configs (N = 1) short legs of the other single-GPU configurations BASELINE.json names -- bf16 G24 (configs[2]'s
+                per-GPU work), fp16 G61 at cs=520 (configs[3]), fp32 at the shipped default tiling (G24d) -- each with its
+                rate, its dominant kernel's roofline, HBM traffic from the matching stored PMC summary, and parity against
+                the oracle on tiles of its timed launch shape
 """
 import argparse
 import ctypes
 import json
+import math
 import os
 import socket
 import subprocess
@@ -91,9 +102,10 @@ def parse():
     ap.add_argument("--frames", type=int, default=0,
                     help="> 0: BASELINE configs[2]'s shape -- a step is this many frames, dealt round-robin to the ranks "
                          "(frame-level sharding, no per-frame exchange)")
-    ap.add_argument("--tile-shard", action="store_true",
-                    help="N > 1: split ONE frame's tiles over the ranks (single-frame latency, strong scaling, P2P row-band exchange) "
-                         "instead of one frame per rank")
+    ap.add_argument("--tile-shard", action="store_true", help="(the default for N > 1; kept for older command lines)")
+    ap.add_argument("--frame-per-rank", action="store_true",
+                    help="N > 1: time N independent replicas (one whole frame per rank per step, no exchange) instead of the tile-sharded stream")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the bf16 G24 / fp16 G61 / fp32 G24d legs of the default single-GPU run")
     ap.add_argument("--cpu-sample-tiles", type=int, default=0,
                     help="0: sized for ~10 s of CPU work per mode; -1: the WHOLE frame, un-extrapolated (minutes: for a kept record)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads of the baseline leg (0: all the cgroup allows, max 64)")
@@ -143,7 +155,9 @@ def spawn_ranks(n):
         time.sleep(0.2)
     rcs = [p.wait() for p in procs]
     reader.join(timeout=10)
-    sys.stdout.write(b"".join(c for c in chunks if c).decode(errors="replace"))
+    # rank 0's stdout carries the one JSON line; anything else a library printed there (gloo's connection banner) goes to stderr
+    for ln in b"".join(c for c in chunks if c).decode(errors="replace").splitlines():
+        (sys.stdout if ln.startswith("{") else sys.stderr).write(ln + "\n")
     sys.stdout.flush()
     if failed or any(rcs):
         sys.exit(f"bench.py: rank exit codes {rcs}")
@@ -294,8 +308,18 @@ def roofline_report(steps, dtype, cs, batch, funit):
 
 # ------------------------------------------------------------------------------------------------ CPU baseline + parity
 
+def sample_runs(total, n, run=8):
+    """Tile ids of the CPU leg: runs of `run` consecutive tiles spread over the frame (the first run starts at tile 0, the last
+    ends at the frame's last tile), ~n tiles in all.  Runs, not isolated tiles: a run's stitched canvas has pixels that no tile
+    outside the run touches, which is what lets the parity leg compare CANVASES of the timed path (fused stitch included)."""
+    run = max(1, min(run, total))
+    nruns = max(1, n // run)
+    starts = [0] if nruns == 1 else [round(k * (total - run) / (nruns - 1)) for k in range(nruns)]
+    return sorted({i for s0 in starts for i in range(s0, s0 + run)})
+
+
 def cpu_baseline(frame, sd, cs, ucs, ol, ids, threads, grad_mode):
-    """The oracle's crop -> UtNet -> stitch on the tiles `ids` of the frame (torch CPU fp32).  Returns (seconds, outputs)."""
+    """The oracle's crop -> UtNet -> stitch on the tiles `ids` of the frame (torch CPU fp32).  Returns (seconds, outputs, tiles)."""
     import numpy as np
     import torch
     from oracle import networks as onet
@@ -318,11 +342,135 @@ def cpu_baseline(frame, sd, cs, ucs, ol, ids, threads, grad_mode):
     return dt, outs, grid.size
 
 
+def canvas_parity(net, img, frame_shape, cs, ucs, ol, batch, ids, outs):
+    """The TIMED path against the oracle.  For every launch of `batch` tiles that holds sampled tiles, pipeline.denoise_frame
+    (fused gather -> conv stack with useful-region layers -> fused stitch, exactly the timed call) stitches the WHOLE launch
+    into a zero canvas; the oracle stitches its outputs of the sampled tiles; the two canvases are compared on the pixels that
+    sampled tiles cover and no other tile of the launch touches."""
+    import numpy as np
+    import torch
+    from nind_denoise_amd import pipeline
+    from oracle import tiler as otiler
+    _, H, W = frame_shape
+    grid = otiler.TileGrid(W, H, cs, ucs, ol)
+    total = grid.size
+    by_launch = {}
+    for k, i in enumerate(ids):
+        by_launch.setdefault(i // batch, []).append((k, i))
+    worst = scale = 0.0
+    sse = 0.0
+    npix = 0
+    lo_v, hi_v = float("inf"), float("-inf")
+    for launch, members in sorted(by_launch.items()):
+        a, b = launch * batch, min(total, (launch + 1) * batch)
+        cv = torch.zeros((3, H, W), dtype=torch.float32, device=img.device)
+        pipeline.denoise_frame(net, img, cs, ucs, ol, batch=batch, tile_range=(a, b), canvas=cv)
+        ref = np.zeros((3, H, W), dtype=np.float32)
+        mine = np.zeros((H, W), dtype=bool)
+        other = np.zeros((H, W), dtype=bool)
+        sampled = {i for _, i in members}
+        for k, i in members:
+            otiler.stitch_add(ref, outs[k], grid, i)
+        for t in range(a, b):
+            _, _, ud, us = grid.geom(t)
+            (mine if t in sampled else other)[us[1]:us[1] + ud[3] - ud[1], us[0]:us[0] + ud[2] - ud[0]] = True
+        m = mine & ~other
+        ys, xs = np.nonzero(m.any(axis=1))[0], np.nonzero(m.any(axis=0))[0]
+        if len(ys) == 0:
+            continue
+        y0, y1, x0, x1 = ys[0], ys[-1] + 1, xs[0], xs[-1] + 1
+        got = cv[:, y0:y1, x0:x1].cpu().numpy()
+        r = ref[:, y0:y1, x0:x1]
+        mm = np.broadcast_to(m[y0:y1, x0:x1], got.shape)
+        d = np.abs(got - r)[mm]
+        worst = max(worst, float(d.max()))
+        scale = max(scale, float(np.abs(r[mm]).max()))
+        sse += float((d.astype(np.float64) ** 2).sum())
+        npix += int(d.size)
+        lo_v, hi_v = min(lo_v, float(r[mm].min())), max(hi_v, float(r[mm].max()))
+        del cv
+    mse = sse / max(npix, 1)
+    psnr = 10 * math.log10((hi_v - lo_v) ** 2 / max(mse, 1e-30)) if npix else float("nan")
+    return {"max_abs": worst, "max_abs_ref": scale, "psnr_db": round(psnr, 2), "tiles": len(ids), "canvas_values_compared": npix,
+            "launches": len(by_launch)}
+
+
+# ------------------------------------------------------------------------------------------------ single-GPU legs
+
+def time_frames(net, img, canvas, cs, ucs, ol, batch, steps, warmup):
+    import torch
+    from nind_denoise_amd import pipeline
+    for _ in range(warmup):
+        canvas.zero_()
+        pipeline.denoise_frame(net, img, cs, ucs, ol, batch=batch, canvas=canvas)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        canvas.zero_()
+        pipeline.denoise_frame(net, img, cs, ucs, ol, batch=batch, canvas=canvas)
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+OTHER_CONFIGS = [
+    # key, BASELINE config, (W, H, cs, ucs, ol), dtype, tiles per launch, parity bar (PSNR dB against the fp32 oracle; None: the fp32 bar)
+    ("bf16_g24", "configs[2] per-GPU work: 24 MP frame, bf16 storage", (6000, 4000, 264, 200, 64), "bf16", 160, 65.0),
+    ("f16_g61", "configs[3]: 61 MP frame (9504x6336), cs=520 (nearest valid to 512), fp16 storage", (9504, 6336, 520, 456, 64), "f16", 40, 85.0),
+    ("f32_g24d", "configs[1] at the shipped default tiling (CS_UTNET, UCS_UTNET = 504, 480, overlap 6)", (6000, 4000, 504, 480, 6), "f32", 64, None),
+]
+
+
+def other_config_leg(key, what, geom, dtype, batch, bar, sd, funit, dev, threads, steps):
+    """One short leg of another single-GPU configuration: rate, dominant-kernel roofline, parity of the timed path."""
+    import torch
+    from nind_denoise_amd import synth
+    from nind_denoise_amd.networks.UtNet import UtNet
+    W, H, cs, ucs, ol = geom
+    net = UtNet(funit=funit)
+    net.load_state_dict(sd)
+    net = net.eval().to(dev).set_compute_dtype(dtype)
+    frame_np = synth.make_frame(W, H, seed=61 if W != 6000 else 24)
+    img = torch.from_numpy(frame_np).to(dev)
+    canvas = torch.zeros_like(img)
+    dt = time_frames(net, img, canvas, cs, ucs, ol, batch, steps, 1)
+    mp = W * H / 1e6
+    from nind_denoise_amd import pipeline
+    total = pipeline.tile_count(W, H, cs, ucs, ol)
+    row = {"what": what, "value": round(mp * steps / dt, 4), "unit": "MP/s", "dtype": dtype, "ms_per_frame": round(1e3 * dt / steps, 3),
+           "frames": steps, "geometry": {"width": W, "height": H, "cs": cs, "ucs": ucs, "ol": ol, "tiles_per_frame": total,
+                                         "tiles_per_launch": batch}}
+    b = min(batch, total)
+    prof = conv_stack_profile(net, cs, b, dev, crop=(cs - ucs) // 2)
+    rf = roofline_report(prof, dtype, cs, b, funit)
+    for k in ("per_layer", "definition"):
+        rf.pop(k, None)
+    row["roofline"] = rf
+    # parity: two runs of 8 tiles (first tiles of the first launch, last tiles of the frame) through the oracle
+    ids = sample_runs(total, 16, run=8)
+    cdt, outs, _ = cpu_baseline(frame_np, sd, cs, ucs, ol, ids, threads, False)
+    par = canvas_parity(net, img, frame_np.shape, cs, ucs, ol, batch, ids, outs)
+    if bar is None:
+        par["bar"] = "fp32: max_abs <= 1e-3 and <= 1e-3 * max_abs_ref"
+        par["ok"] = bool(par["max_abs"] <= 1e-3 and par["max_abs"] <= 1e-3 * par["max_abs_ref"])
+    else:
+        par["bar"] = f"16-bit storage against the fp32 oracle: PSNR >= {bar} dB"
+        par["ok"] = bool(par["psnr_db"] >= bar)
+    par["note"] = (f"timed path (pipeline.denoise_frame, {batch} tiles per launch, useful-region layers, fused stitch) vs the oracle's "
+                   f"stitched canvas of {len(ids)} tiles ({cdt:.1f} s of torch CPU)")
+    row["parity"] = par
+    del net, img, canvas
+    torch.cuda.empty_cache()
+    return row
+
+
+# ------------------------------------------------------------------------------------------------ main
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus)
         return
+    import datetime
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -341,22 +489,31 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # (a rank that dies takes the others out of their collectives within this timeout instead of hanging them)
+        tmo = datetime.timedelta(seconds=300)
         if REHEARSAL:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
     _lib.load()
 
     W, H, cs, ucs, ol = args.width, args.height, args.cs, args.ucs, args.ol
-    sd = synth.make_utnet_state_dict(funit=args.funit, seed=123)
+    # rank 0 owns the model (seeded synthetic weights with the reference's state-dict layout); the other ranks start from
+    # different values and receive the raw parameters by broadcast, then pack them on their own device
+    sd = synth.make_utnet_state_dict(funit=args.funit, seed=123 if rank == 0 else 1000 + rank)
     net = UtNet(funit=args.funit)
     net.load_state_dict(sd)
     net = net.eval().to(dev).set_compute_dtype(args.dtype)
     net.winograd = not args.no_winograd
     net.useful_only = not args.whole_tiles
-    blob = net.packed_weights(dev)
-    if world > 1 and not REHEARSAL:
-        dist.broadcast(blob, src=0)  # one-time weight broadcast (rank 0 is the model owner)
+    bcast = None
+    if world > 1:
+        t0 = time.perf_counter()
+        nbytes = ndist.broadcast_parameters(net, src=0)
+        torch.cuda.synchronize()
+        bcast = {"bytes": nbytes, "seconds": round(time.perf_counter() - t0, 4),
+                 "what": "raw state-dict tensors as one flat fp32 buffer from rank 0; every rank packs them on its own device"}
+    net.packed_weights(dev)
 
     geo = ndist.Geo(W, H, cs, ucs, ol)
     total = geo.total
@@ -366,69 +523,125 @@ def main():
     def compute(fr, cv, a, b):
         pipeline.denoise_frame(net, fr, cs, ucs, ol, batch=args.batch, tile_range=(a, b), canvas=cv)
 
-    weak = world > 1 and args.frames == 0 and not args.tile_shard
-    if weak:
-        args.frames = world   # one frame per rank per step: per-GPU work fixed as N grows
-    if args.frames > 0:
-        # configs[2] shape: a step = `frames` frames, frame f handled by rank f % world; a few distinct synthetic frames
-        # resident in HBM are cycled (the arithmetic does not depend on the pixel values)
-        mine = ndist.frame_shard(args.frames, rank, world)
-        pool = [torch.from_numpy(synth.make_frame(W, H, seed=s)).to(dev) for s in range(min(3, max(1, len(mine))))]
-        if rank == 0:
-            frame_np = pool[0].cpu().numpy()
-        canvas = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
-        lo, hi = 0, total
-
-        def step():
-            for k, _f in enumerate(mine):
-                canvas.zero_()
-                compute(pool[k % len(pool)], canvas, 0, total)
-        frames_per_step = args.frames
-    else:
-        frame_np = synth.make_frame(W, H, seed=24) if rank == 0 else None
-        frame = torch.from_numpy(frame_np).to(dev) if rank == 0 else torch.empty((3, H, W), dtype=torch.float32, device=dev)
-        lo, hi = geo.shard(rank, world)
-        canvas = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
-
-        def step():
-            if world > 1:
-                # rank 0 scatters input row bands, every rank denoises its tile shard, rank 0 gathers + adds the bands
-                ndist.denoise_frame_sharded(compute, frame, canvas, geo)
-            else:
-                canvas.zero_()
-                compute(frame, canvas, 0, total)
-        frames_per_step = 1
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    log(f"setup done: {total} tiles/frame, rank tile shard [{lo},{hi}), batch {args.batch}, frames/step {frames_per_step}")
-    for i in range(args.warmup):
-        step()
+    mode = "single" if world == 1 and args.frames == 0 else ("frames" if args.frames > 0 else ("replicas" if args.frame_per_rank else "tile-stream"))
+    lo, hi = geo.shard(rank, world) if mode == "tile-stream" else (0, total)
+    # a few distinct synthetic frames resident in HBM are cycled (the arithmetic does not depend on the pixel values)
+    if rank == 0 or mode in ("frames", "replicas"):
+        frame_np = synth.make_frame(W, H, seed=24)
+        pool = [torch.from_numpy(frame_np).to(dev)] + [torch.from_numpy(synth.make_frame(W, H, seed=s_)).to(dev) for s_ in (25, 26)]
+    else:
+        pool = []
+    canvas = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
+
+    def replica_steps(n, frames_in_step):
+        mine = ndist.frame_shard(frames_in_step, rank, world)
+        for _ in range(n):
+            for k, _f in enumerate(mine):
+                canvas.zero_()
+                compute(pool[k % len(pool)], canvas, 0, total)
+
+    stream = None
+    if mode == "tile-stream":
+        stream = ndist.ShardedFrameStream(compute, geo, dev)
+
+        def run_steps(n):
+            src = (pool[k % len(pool)] for k in range(n)) if rank == 0 else None
+            for _k, _cv in stream.run(src, n):
+                pass
+        frames_per_step = 1
+    elif mode == "single":
+        def run_steps(n):
+            for _ in range(n):
+                canvas.zero_()
+                compute(pool[0], canvas, 0, total)
+        frames_per_step = 1
+    else:
+        frames_per_step = args.frames if mode == "frames" else world
+
+        def run_steps(n):
+            replica_steps(n, frames_per_step)
+
+    log(f"setup done: {total} tiles/frame, mode {mode}, rank tile shard [{lo},{hi}), batch {args.batch}, frames/step {frames_per_step}")
+    if args.warmup > 0:
+        run_steps(args.warmup)
         torch.cuda.synchronize()
-        log(f"warmup step {i} done")
+        log(f"{args.warmup} warmup step(s) done")
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     log(f"timed {args.steps} steps in {dt:.3f} s")
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if REHEARSAL else dev)
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if REHEARSAL else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        return float(t.item())
+
+    dt = max_over_ranks(dt)
+    extra = {}
+    if mode == "tile-stream":
+        # compute-only time of this rank's shard (no exchange): what a step would cost if the exchange were free
+        compute(pool[0] if rank == 0 else stream.frames[0], stream.canvas[0], lo, hi)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        nc = max(2, min(4, args.steps))
+        for _ in range(nc):
+            compute(pool[0] if rank == 0 else stream.frames[0], stream.canvas[0], lo, hi)
+        torch.cuda.synchronize()
+        tc = max_over_ranks((time.perf_counter() - t1) / nc)
+        extra["pipeline"] = {"ms_per_step": round(1e3 * dt / args.steps, 3), "compute_only_ms_largest_shard": round(1e3 * tc, 3),
+                             "exchange_hidden_frac": round(min(1.0, tc / (dt / args.steps)), 4),
+                             "note": "compute_only = this mode's per-rank shard loop with no exchange, max over ranks; a step of the pipelined "
+                                     "stream costs max(compute, exchange) + fill/drain of two exchange steps per timed region"}
+        # secondary key: N independent replicas (one whole frame per rank per step; no data-path traffic) -- NOT the metric
+        if rank != 0:
+            frame_np = synth.make_frame(W, H, seed=24)
+            pool = [torch.from_numpy(frame_np).to(dev)]
+        nr = max(1, min(3, args.steps))
+        replica_steps(1, world)
+        barrier()
+        t2 = time.perf_counter()
+        replica_steps(nr, world)
+        barrier()
+        tr = max_over_ranks(time.perf_counter() - t2)
+        extra["frame_shard"] = {"value": round(mp * world * nr / tr, 4), "unit": "MP/s", "frames_per_step": world, "steps": nr,
+                                "note": "REPLICAS: one whole frame per rank per step, no data-path collective -- reported for reference, not the metric"}
+    if world > 1 and rank != 0:
+        # the post-timing legs are rank 0's alone and contain no collective: the other ranks are done
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    if world > 1:
+        dist.barrier()
 
     value = mp * frames_per_step * args.steps / dt
     cfg_idx = 1 if args.dtype == "f32" else 2 if args.dtype == "bf16" else 3
-    if args.frames > 0:
+    if mode == "frames":
         par = f"frame-shard x{world} (frames dealt round-robin, no per-frame exchange)" if world > 1 else "single GPU"
         what = f"{args.frames} {W}x{H} ({mp:.1f} MP) fp32 frames per step"
+        scaling = "strong" if world > 1 else "none"
+    elif mode == "replicas":
+        par = f"replicas x{world} (one whole frame per rank per step, no data-path collective)"
+        what = f"{world} {W}x{H} ({mp:.1f} MP) fp32 frames per step, one per rank"
+        scaling = "weak"
+    elif mode == "tile-stream":
+        par = (f"tile-shard x{world}: every frame's tile loop split into {world} contiguous tile-index shards; rank 0 scatters input row bands and "
+               "gathers + adds canvas row bands point-to-point (RCCL over xGMI), pipelined across frames (scatter of n+1 / gather of n-1 under "
+               "the compute of n); weights broadcast once as raw parameters")
+        what = f"one {W}x{H} ({mp:.1f} MP) fp32 frame per step, entering and leaving through rank 0"
+        scaling = "strong"
     else:
-        par = f"tile-shard x{world} (P2P row-band scatter / gather at rank 0)" if world > 1 else "single GPU"
+        par = "single GPU"
         what = f"one {W}x{H} ({mp:.1f} MP) fp32 frame per step"
+        scaling = "none"
     out = {
         "metric": METRIC,
         "value": round(value, 4),
@@ -438,7 +651,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 3),
         "higher_is_better": True,
-        "scaling": "weak" if (weak or world == 1) else "strong",
+        "scaling": scaling,
         "vs_baseline": None,
         "dtype": args.dtype,
         "data": "synthetic" + (" -- REHEARSAL: all ranks on one GPU over gloo, not a benchmark result" if REHEARSAL else ""),
@@ -455,106 +668,92 @@ def main():
             "parallelism": par,
         },
     }
+    out.update(extra)
+    if bcast:
+        out["weight_broadcast"] = bcast
 
-    if rank == 0:
-        flop_frame = net.flops_per_tile(cs) * total
-        out["end_to_end_algorithmic_tflops"] = round(flop_frame * frames_per_step * args.steps / dt / 1e12, 3)
-        if not args.no_roofline:
-            # (N > 1: rank 0 profiles the conv stack at the size of its own tile shard; the other ranks wait at the end)
-            b = min(args.batch, hi - lo)
-            steps = conv_stack_profile(net, cs, b, dev, crop=(cs - ucs) // 2)
-            log("conv stack profile done")
-            out["roofline"] = roofline_report(steps, args.dtype, cs, b, args.funit)
-            out["config"]["computed_flop_per_frame"] = sum(s_["flop"] for s_ in steps) / b * total   # conv stack, regions counted as computed
-        if world == 1 and not args.whole_tiles and args.frames == 0 and not args.no_whole_leg:
-            # the same frame with every layer on whole tiles (what UtNet.forward computes): its rate, and the two canvases compared
-            cv_roi = canvas.clone()
-            net.useful_only = False
-            step()
-            torch.cuda.synchronize()
-            tw = time.perf_counter()
-            nw = max(2, min(4, args.steps))
-            for _ in range(nw):
-                step()
-            torch.cuda.synchronize()
-            tw = time.perf_counter() - tw
-            diff = float((canvas - cv_roi).abs().max().item())
-            out["whole_tiles"] = {"value": round(mp * nw / tw, 4), "unit": "MP/s", "frames": nw,
-                                  "canvas_max_abs_diff": diff, "canvas_max_abs": float(cv_roi.abs().max().item()),
-                                  "note": "ND_FLAG_FULL_TILES: every layer computes its whole tile; canvas_max_abs_diff = max |canvas - canvas of the "
-                                          "timed (useful-region) loop| over the whole frame"}
-            net.useful_only = True
-            del cv_roi
-            log(f"whole-tile leg: {out['whole_tiles']['value']} MP/s, canvases differ by {diff:.2e}")
-        if not args.no_host_leg and world == 1:
-            # SURVEY.md 8(d)'s end-to-end definition: decoded fp32 frame in pinned host memory -> stitched frame in host memory,
-            # through the resident engine (H2D / compute / D2H overlapped over a ring of 3 slots).  Reported beside `value`.
-            from nind_denoise_amd.serve import FrameEngine
-            eng = FrameEngine(net, W, H, cs, ucs, ol, batch=args.batch, slots=3, device=dev)
-            src = torch.from_numpy(frame_np).pin_memory()
-            n_host = max(4, min(12, args.steps))
-            for _ in eng.run([src] * 2):
-                pass
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            cnt = 0
-            for _ in eng.run([src] * n_host, copy=False):
-                cnt += 1
-            dth = time.perf_counter() - t1
-            out["host_to_host"] = {"value": round(mp * cnt / dth, 4), "unit": "MP/s", "frames": cnt,
-                                   "note": "pinned host frame -> HBM -> crop/UtNet/stitch -> pinned host canvas, PCIe legs overlapped "
-                                           "with compute (serve.FrameEngine); `value` above is the HBM-resident rate"}
-            del eng
-            log("host-to-host leg done")
-        if not args.no_cpu_baseline and world == 1:
-            threads = args.cpu_threads or min(host_cores(), 64)
-            n = args.cpu_sample_tiles or max(8, min(200, threads * 6))   # ~10 s of CPU work per mode at ~0.1 s/tile
-            if n < 0:
-                n = total
-            ids = [int(i) for i in np.linspace(0, total - 1, n)]
-            log(f"cpu baseline: {n} tiles on {threads} threads, grad mode then no_grad")
-            cdt_g, _, tot = cpu_baseline(frame_np, sd, cs, ucs, ol, ids, threads, True)
-            cdt_n, outs, _ = cpu_baseline(frame_np, sd, cs, ucs, ol, ids, threads, False)
-            log(f"cpu baseline done in {cdt_g:.1f} + {cdt_n:.1f} s")
-            out["cpu_baseline"] = {
-                "value": round(mp * (n / tot) / cdt_g, 5),
-                "unit": "MP/s",
-                "cores": threads,
-                "kind": "port",
-                "sample": (f"the whole frame, un-extrapolated: all {tot} tiles" if n == tot else f"{n} of {tot} tiles of the same frame")
-                          + f" through oracle gather -> UtNet (torch CPU fp32, {threads} threads) -> stitch" + ("" if n == tot else ", scaled by tiles")
-                          + f"; grad mode as the reference runs (denoise_image.py:246, no no_grad) in {cdt_g:.2f} s",
-                "no_grad": {"value": round(mp * (n / tot) / cdt_n, 5), "seconds": round(cdt_n, 2)},
-            }
-            # parity of the timed HIP path on those same tiles (the launch shape of the timed loop: `batch` tiles per launch)
-            img = torch.from_numpy(frame_np).to(dev)
-            worst = 0.0
-            scale = 0.0
-            psnr_min = float("inf")
-            per_launch = {}
-            for k, i in enumerate(ids):
-                per_launch.setdefault(i // args.batch, []).append((k, i))
-            for launch, members in per_launch.items():
-                first = launch * args.batch
-                cnt = min(args.batch, total - first)
-                x = pipeline.gather_tiles(img, cs, ucs, ol, first, cnt)
-                y = net(x)
-                for k, i in members:
-                    got = y[i - first].cpu().numpy()
-                    ref = outs[k]
-                    worst = max(worst, float(np.abs(got - ref).max()))
-                    scale = max(scale, float(np.abs(ref).max()))
-                    mse = float(np.mean((got - ref) ** 2))
-                    psnr_min = min(psnr_min, 10 * np.log10(float(ref.max() - ref.min()) ** 2 / max(mse, 1e-30)))
-                del x, y
-            out["parity"] = {"max_abs": worst, "max_abs_ref": scale, "min_psnr_db": round(psnr_min, 2), "tiles": n,
-                             "bar": "fp32: max_abs <= 1e-3 and <= 1e-3 * max_abs_ref" if args.dtype == "f32" else "16-bit storage: PSNR reported",
-                             "ok": bool(worst <= 1e-3 and worst <= 1e-3 * scale) if args.dtype == "f32" else bool(psnr_min >= 60.0),
-                             "note": f"HIP path at the timed launch shape ({args.batch} tiles per launch) vs the oracle outputs of the cpu_baseline leg"}
-            log(f"parity on {n} tiles: max abs {worst:.3e}")
-        print(json.dumps(out))
+    flop_frame = net.flops_per_tile(cs) * total
+    out["end_to_end_algorithmic_tflops"] = round(flop_frame * frames_per_step * args.steps / dt / 1e12, 3)
+    if not args.no_roofline:
+        # (N > 1: rank 0 profiles the conv stack at the launch size of its own tile shard)
+        b = min(args.batch, hi - lo)
+        steps = conv_stack_profile(net, cs, b, dev, crop=(cs - ucs) // 2)
+        log("conv stack profile done")
+        out["roofline"] = roofline_report(steps, args.dtype, cs, b, args.funit)
+        out["config"]["computed_flop_per_frame"] = sum(s_["flop"] for s_ in steps) / b * total   # conv stack, regions counted as computed
+    if mode == "single" and not args.whole_tiles and not args.no_whole_leg:
+        # the same frame with every layer on whole tiles (what UtNet.forward computes): its rate, and the two canvases compared
+        cv_roi = canvas.clone()
+        net.useful_only = False
+        nw = max(2, min(4, args.steps))
+        tw = time_frames(net, pool[0], canvas, cs, ucs, ol, args.batch, nw, 1)
+        diff = float((canvas - cv_roi).abs().max().item())
+        out["whole_tiles"] = {"value": round(mp * nw / tw, 4), "unit": "MP/s", "frames": nw,
+                              "canvas_max_abs_diff": diff, "canvas_max_abs": float(cv_roi.abs().max().item()),
+                              "note": "ND_FLAG_FULL_TILES: every layer computes its whole tile; canvas_max_abs_diff = max |canvas - canvas of the "
+                                      "timed (useful-region) loop| over the whole frame"}
+        net.useful_only = True
+        del cv_roi
+        log(f"whole-tile leg: {out['whole_tiles']['value']} MP/s, canvases differ by {diff:.2e}")
+    if not args.no_host_leg and mode == "single":
+        # SURVEY.md 8(d)'s end-to-end definition: decoded fp32 frame in pinned host memory -> stitched frame in host memory,
+        # through the resident engine (H2D / compute / D2H overlapped over a ring of 3 slots).  Reported beside `value`.
+        from nind_denoise_amd.serve import FrameEngine
+        eng = FrameEngine(net, W, H, cs, ucs, ol, batch=args.batch, slots=3, device=dev)
+        src = torch.from_numpy(frame_np).pin_memory()
+        n_host = max(4, min(12, args.steps))
+        for _ in eng.run([src] * 2):
+            pass
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        cnt = 0
+        for _ in eng.run([src] * n_host, copy=False):
+            cnt += 1
+        dth = time.perf_counter() - t1
+        out["host_to_host"] = {"value": round(mp * cnt / dth, 4), "unit": "MP/s", "frames": cnt,
+                               "note": "pinned host frame -> HBM -> crop/UtNet/stitch -> pinned host canvas, PCIe legs overlapped "
+                                       "with compute (serve.FrameEngine); `value` above is the HBM-resident rate"}
+        del eng
+        log("host-to-host leg done")
+    threads = args.cpu_threads or min(host_cores(), 64)
+    if not args.no_cpu_baseline and world == 1:
+        n = args.cpu_sample_tiles or max(8, min(200, threads * 6))   # ~10 s of CPU work per mode at ~0.1 s/tile
+        ids = list(range(total)) if n < 0 else sample_runs(total, n, run=8)
+        n = len(ids)
+        log(f"cpu baseline: {n} tiles on {threads} threads, grad mode then no_grad")
+        cdt_g, _, tot = cpu_baseline(frame_np, sd, cs, ucs, ol, ids, threads, True)
+        cdt_n, outs, _ = cpu_baseline(frame_np, sd, cs, ucs, ol, ids, threads, False)
+        log(f"cpu baseline done in {cdt_g:.1f} + {cdt_n:.1f} s")
+        out["cpu_baseline"] = {
+            "value": round(mp * (n / tot) / cdt_g, 5),
+            "unit": "MP/s",
+            "cores": threads,
+            "kind": "port",
+            "sample": (f"the whole frame, un-extrapolated: all {tot} tiles" if n == tot else f"{n} of {tot} tiles of the same frame (runs of 8 consecutive tiles)")
+                      + f" through oracle gather -> UtNet (torch CPU fp32, {threads} threads) -> stitch" + ("" if n == tot else ", scaled by tiles")
+                      + f"; grad mode as the reference runs (denoise_image.py:246, no no_grad) in {cdt_g:.2f} s",
+            "no_grad": {"value": round(mp * (n / tot) / cdt_n, 5), "seconds": round(cdt_n, 2)},
+        }
+        par_ = canvas_parity(net, pool[0], frame_np.shape, cs, ucs, ol, args.batch, ids, outs)
+        par_["bar"] = "fp32: max_abs <= 1e-3 and <= 1e-3 * max_abs_ref" if args.dtype == "f32" else "16-bit storage: PSNR >= 60 dB against the fp32 oracle"
+        par_["ok"] = bool(par_["max_abs"] <= 1e-3 and par_["max_abs"] <= 1e-3 * par_["max_abs_ref"]) if args.dtype == "f32" else bool(par_["psnr_db"] >= 60.0)
+        par_["note"] = (f"the TIMED path -- pipeline.denoise_frame: fused gather -> conv stack ("
+                        + ("whole-tile layers" if args.whole_tiles else "useful-region layers") + f") -> fused stitch, whole launches of {args.batch} tiles "
+                        "-- stitched into a zero canvas, against the oracle's stitched canvas of the cpu_baseline tiles, on the pixels only those tiles touch")
+        out["parity"] = par_
+        log(f"parity on {n} tiles ({par_['canvas_values_compared']} canvas values): max abs {par_['max_abs']:.3e}")
+    if mode == "single" and not args.no_other_configs and args.dtype == "f32" and (W, H, cs, ucs, ol) == (6000, 4000, 264, 200, 64):
+        del pool, canvas
+        net._workspaces.clear()
+        torch.cuda.empty_cache()
+        out["other_configs"] = {}
+        sd0 = synth.make_utnet_state_dict(funit=args.funit, seed=123)
+        for key, what_, geom, dtype_, batch_, bar in OTHER_CONFIGS:
+            out["other_configs"][key] = other_config_leg(key, what_, geom, dtype_, batch_, bar, sd0, args.funit, dev, threads, steps=3)
+            log(f"other config {key}: {out['other_configs'][key]['value']} MP/s, dominant kernel frac "
+                f"{out['other_configs'][key]['roofline']['frac']}, parity {out['other_configs'][key]['parity']}")
+    print(json.dumps(out))
     if world > 1:
-        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -9,10 +9,19 @@ through libnind_hip.so (pipeline.denoise_frame).
 egrun:
     python -m nind_denoise_amd.denoise_image --network UtNet --model_path generator_650.pt -i in.tif -o out.tiff
 '''
-import argparse
-import math
 import os
 import sys
+
+if __name__ == '__main__':
+    # thin-client mode (--server PATH or NIND_DENOISE_SERVER): hand the arguments to the resident worker BEFORE anything heavy is
+    # imported -- neither torch nor libnind_hip.so is loaded in this process (nind_denoise_amd/client.py, serve.py)
+    from nind_denoise_amd import client as _client
+    _server, _rest = _client.split_server_arg(sys.argv[1:])
+    if _server is not None:
+        sys.exit(_client.request(_server, {'argv': _rest, 'cwd': os.getcwd()}))
+
+import argparse
+import math
 import time
 
 import torch
@@ -141,9 +150,11 @@ def build_parser():
     return parser
 
 
-def parse_args(argv=None):
+def parse_args(argv=None, cwd=None):
     parser = build_parser()
     args, _ = parser.parse_known_args(argv)
+    if cwd is not None and args.config and not os.path.isabs(args.config):
+        args.config = os.path.join(cwd, args.config)    # (a worker's request: the client's directory)
     # configargparse behaviour of the reference: values of the default YAML file fill options left unset
     if args.config and os.path.isfile(args.config):
         with open(args.config, 'r') as f:
@@ -177,12 +188,12 @@ def _save_dbg_jpg(t, path):
     Image.fromarray(arr).save(path)
 
 
-def _denoise_frame_debug(model, ds, cs, ucs, overlap, batch, outpath):
+def _denoise_frame_debug(model, ds, cs, ucs, overlap, batch, outpath, dbg_dir='dbg'):
     """--debug (denoise_image.py:149-150, 260-269): the loop tile by tile with the reference's crop dumps in ./dbg --
     crop<batch>_<i>_denoised.jpg (the network's whole output tile), _tensimg.jpg (useful crop with halved overlap strips),
     _noisy.jpg (the input tile) -- and the last output tile with its borders as <output>dbg_inclborders.tif.  The canvas
     is built by the same device stitch kernel as the fast path (identical result, just not fused)."""
-    os.makedirs('dbg', exist_ok=True)
+    os.makedirs(dbg_dir, exist_ok=True)
     img = ds.inimg
     H, W = img.size(1), img.size(2)
     canvas = torch.zeros_like(img)
@@ -205,9 +216,9 @@ def _denoise_frame_debug(model, ds, cs, ucs, overlap, batch, outpath):
                 tensimg[:, :, -overlap:] /= 2
             if absy0 + ucs < H and overlap:
                 tensimg[:, -overlap:, :] /= 2
-            _save_dbg_jpg(xbatch[i], 'dbg/crop' + str(n_count) + '_' + str(i) + '_denoised.jpg')
-            _save_dbg_jpg(tensimg, 'dbg/crop' + str(n_count) + '_' + str(i) + '_tensimg.jpg')
-            _save_dbg_jpg(ybatch[i], 'dbg/crop' + str(n_count) + '_' + str(i) + '_noisy.jpg')
+            _save_dbg_jpg(xbatch[i], dbg_dir + '/crop' + str(n_count) + '_' + str(i) + '_denoised.jpg')
+            _save_dbg_jpg(tensimg, dbg_dir + '/crop' + str(n_count) + '_' + str(i) + '_tensimg.jpg')
+            _save_dbg_jpg(ybatch[i], dbg_dir + '/crop' + str(n_count) + '_' + str(i) + '_noisy.jpg')
             print(tensimg.shape)
             print((absx0, absy0, ud))
             last = xbatch[i]
@@ -217,38 +228,63 @@ def _denoise_frame_debug(model, ds, cs, ucs, overlap, batch, outpath):
 
 
 def denoise_file(model, inpath, outpath, cs, ucs, overlap, batch=32, whole_image=False, pad=None, max_subpixels=None,
-                 device=None, verbose=True, debug=False):
+                 device=None, verbose=True, debug=False, gpu_lock=None, dbg_dir='dbg'):
     '''One image file through the device-resident crop -> infer -> stitch loop (the body of the reference's __main__,
-    denoise_image.py:228-270); also what denoise_dir runs per image, in process, instead of spawning this script.'''
-    ds = OneImageDS(inpath, cs, ucs, overlap, whole_image=whole_image, pad=pad, device=device)
-    if whole_image:
-        ybatch, usefuldims, _ = ds[0]
-        ybatch = ybatch[None]
-        if max_subpixels is not None and math.prod(ybatch.shape) > max_subpixels:
-            sys.exit(f'denoise_image.py: {ybatch.shape=}, {math.prod(ybatch.shape)=} > {max_subpixels=} for {inpath=}; aborting')
-        ud = usefuldims.tolist()
-        newimg = model(ybatch)[0][:, ud[1]:ud[3], ud[0]:ud[2]]
-    else:
-        if max_subpixels is not None and batch * 3 * cs * cs > max_subpixels:
-            batch = max(1, max_subpixels // (3 * cs * cs))
-            if 3 * cs * cs > max_subpixels:
-                sys.exit(f'denoise_image.py: tile of {3 * cs * cs} sub-pixels > {max_subpixels=} for {inpath=}; aborting')
-        nbatches = int(math.ceil(len(ds) / batch))
-
-        def progress(n, t0, cnt):
-            if verbose:
-                print(str(n) + '/' + str(nbatches))
-        if debug:
-            newimg = _denoise_frame_debug(model, ds, cs, ucs, overlap, batch, outpath)
+    denoise_image.py:228-270); also what denoise_dir runs per image, in process, instead of spawning this script.
+    gpu_lock (resident worker): held for the device section only, so that the decode of one request and the encode of another
+    overlap a third one's GPU time.'''
+    import contextlib
+    device = torch.device(device) if device is not None else nn_common.default_device()
+    if device is None or device.type != 'cuda':
+        raise RuntimeError('denoise_file: no GPU; nind_denoise_amd has no CPU fallback')
+    frame = torch.from_numpy(np_imgops.img_path_to_np_flt(inpath)) if isinstance(inpath, (str, os.PathLike)) else inpath
+    with (gpu_lock if gpu_lock is not None else contextlib.nullcontext()):
+        ds = OneImageDS(frame, cs, ucs, overlap, whole_image=whole_image, pad=pad, device=device)
+        if whole_image:
+            ybatch, usefuldims, _ = ds[0]
+            ybatch = ybatch[None]
+            if max_subpixels is not None and math.prod(ybatch.shape) > max_subpixels:
+                sys.exit(f'denoise_image.py: {ybatch.shape=}, {math.prod(ybatch.shape)=} > {max_subpixels=} for {inpath=}; aborting')
+            ud = usefuldims.tolist()
+            newimg = model(ybatch)[0][:, ud[1]:ud[3], ud[0]:ud[2]]
         else:
-            newimg = pipeline.denoise_frame(model, ds.inimg, cs, ucs, overlap, batch=batch, progress=progress)
-    torch.cuda.synchronize()
-    pt_helpers.tensor_to_imgfile(newimg.cpu(), outpath)
+            if max_subpixels is not None and batch * 3 * cs * cs > max_subpixels:
+                batch = max(1, max_subpixels // (3 * cs * cs))
+                if 3 * cs * cs > max_subpixels:
+                    sys.exit(f'denoise_image.py: tile of {3 * cs * cs} sub-pixels > {max_subpixels=} for {inpath=}; aborting')
+            nbatches = int(math.ceil(len(ds) / batch))
+
+            def progress(n, t0, cnt):
+                if verbose:
+                    print(str(n) + '/' + str(nbatches))
+            if debug:
+                newimg = _denoise_frame_debug(model, ds, cs, ucs, overlap, batch, outpath, dbg_dir)
+            else:
+                newimg = pipeline.denoise_frame(model, ds.inimg, cs, ucs, overlap, batch=batch, progress=progress)
+        host = newimg.cpu()       # (synchronises: the device section ends here)
+    pt_helpers.tensor_to_imgfile(host, outpath)
     return newimg
 
 
-def main(argv=None):
-    args = parse_args(argv)
+def _absolutize(args, cwd):
+    '''A worker runs requests of clients that live in other working directories: resolve their relative paths there.'''
+    for name in ('input', 'output', 'config', 'models_dpath'):
+        v = getattr(args, name, None)
+        if v and not os.path.isabs(v):
+            setattr(args, name, os.path.join(cwd, v))
+    v = args.model_path
+    if v and not os.path.isabs(v) and os.path.exists(os.path.join(cwd, v)):   # (else: a model NAME under models_dpath)
+        args.model_path = os.path.join(cwd, v)
+
+
+def main(argv=None, cwd=None, model_cache=None, gpu_lock=None):
+    '''The reference's __main__ (denoise_image.py:215-283).  cwd / model_cache / gpu_lock are the resident worker's
+    (serve.py): relative paths resolve against the client's directory, a model loaded for one request stays resident (packed
+    weights and workspace with it) for the next, and the device section of concurrent requests is serialised while their
+    file I/O overlaps.'''
+    args = parse_args(argv, cwd)
+    if cwd is not None:
+        _absolutize(args, cwd)
     assert args.model_path is not None
     autodetect_network_cs_ucs(args)
     if not torch.cuda.is_available():
@@ -263,14 +299,26 @@ def main(argv=None):
     if args.g_network == 'UtNet' and not args.whole_image and not valid_cs(args.cs):
         sys.exit(f'denoise_image: --cs {args.cs} is not a valid UtNet tile size (16k+56, e.g. {nearest_valid_cs(args.cs)}); '
                  'the reference network fails on it too')
-    model = nn_common.Model.instantiate_model(network=args.g_network, model_path=args.model_path,
+
+    def load():
+        m = nn_common.Model.instantiate_model(network=args.g_network, model_path=args.model_path,
                                               strparameters=args.model_parameters, keyword='generator',
                                               device=device, models_dpath=args.models_dpath)
-    model.eval()
-    model = model.to(device)
+        m.eval()
+        return m.to(device)
+    if model_cache is None:
+        model = load()
+    else:
+        path = nn_common.Model.complete_path(path=args.model_path, keyword='generator', models_dpath=args.models_dpath)
+        st = os.stat(path)
+        key = (args.g_network, os.path.realpath(path), st.st_mtime_ns, st.st_size, args.model_parameters or '', str(device))
+        model = model_cache.get(key)
+        if model is None:
+            model = model_cache[key] = load()
     start_time = time.time()
     denoise_file(model, args.input, args.output, args.cs, args.ucs, args.overlap, batch=args.batch_size or 64,
-                 whole_image=args.whole_image, pad=args.pad, max_subpixels=args.max_subpixels, device=device, debug=args.debug)
+                 whole_image=args.whole_image, pad=args.pad, max_subpixels=args.max_subpixels, device=device, debug=args.debug,
+                 gpu_lock=gpu_lock, dbg_dir=os.path.join(cwd, 'dbg') if cwd is not None else 'dbg')
     print(f'Denoised image written to {args.output}')
     copy_exif(args)
     print(f'Wrote denoised image to {args.output}')

@@ -321,6 +321,30 @@ def denoise_frames_sharded(denoise, frames, group=None, collect=True):
     return out
 
 
+def broadcast_parameters(module, src=0, group=None):
+    """Rank `src` owns the model: ONE broadcast of its raw parameters as a flat fp32 buffer in state-dict order (124 MB for
+    UtNet(64)); every rank then packs them into MFMA fragment order on its own device (the packed fp32 blob with its Winograd
+    forms is 926 MB: 7x the wire traffic for bytes each rank rebuilds in milliseconds).  Returns the bytes broadcast."""
+    params = list(module.parameters())
+    if not params:
+        return 0
+    flat = torch.cat([p.detach().reshape(-1).to(torch.float32) for p in params])
+    if dist.get_world_size(group) > 1:
+        if flat.is_cuda and _host_staged(group):
+            h = flat.cpu()
+            dist.broadcast(h, src, group)
+            flat = h.to(flat.device)
+        else:
+            dist.broadcast(flat, src, group)
+    off = 0
+    with torch.no_grad():
+        for p in params:
+            n = p.numel()
+            p.copy_(flat[off:off + n].view_as(p))     # (bumps the parameter's version: UtNet re-packs on next use)
+            off += n
+    return flat.numel() * 4
+
+
 def average_gradients(flat, group=None):
     """Data-parallel training (BASELINE config 5): ONE all-reduce of the flat state-dict-order gradient buffer
     (124 MB fp32 for UtNet(64)), then the mean.  No-op without an initialised process group."""

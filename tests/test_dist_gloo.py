@@ -222,3 +222,36 @@ def test_pipelined_frame_stream_matches_single_rank(world, n_frames):
         assert np.isfinite(got[k]).all()
         assert np.abs(got[k] - ref).max() <= 1e-6      # seam rows re-associated (<= 1 ulp), the rest identical
         assert (got[k] == ref).mean() > 0.7
+
+
+def _bcast_worker(rank, world, port, outq):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nind_denoise_amd import dist as ndist
+        torch.manual_seed(rank)          # every rank starts from different values
+        m = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.PReLU(), torch.nn.ConvTranspose2d(8, 3, 2, stride=2))
+        n = ndist.broadcast_parameters(m, src=0)
+        outq.put((rank, n, {k: v.numpy().copy() for k, v in m.state_dict().items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_parameter_broadcast_world_2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bcast_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, n0, sd0), (r1, n1, sd1) = sorted(got, key=lambda t: t[0])
+    torch.manual_seed(0)
+    ref = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.PReLU(), torch.nn.ConvTranspose2d(8, 3, 2, stride=2)).state_dict()
+    assert n0 == n1 == 4 * sum(v.numel() for v in ref.values())
+    for k, v in ref.items():
+        assert np.array_equal(sd0[k], v.numpy()) and np.array_equal(sd1[k], v.numpy())

@@ -573,6 +573,68 @@ def test_cli_end_to_end(dev, tmp_path):
     assert ud.dtype == torch.int32
 
 
+def test_resident_worker_serves_cli_clients(dev, tmp_path):
+    """Row f2: `python -m nind_denoise_amd.serve --socket PATH` started once, three images through
+    `python -m nind_denoise_amd.denoise_image ... --server PATH` clients (fresh light processes that load neither torch nor the
+    HIP library), relative paths resolved in the client's directory, the reference's printed lines relayed, the second and
+    third request served by the resident model; outputs == the oracle loop, as in test_cli_end_to_end.  A failing request
+    returns its status and message and leaves the worker up."""
+    import subprocess
+    import sys
+    import time
+    from nind_denoise_amd.common.libs import imgcodec, np_imgops
+    from oracle import networks as onet
+    from oracle import tiler as otiler
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sd = synth.make_utnet_state_dict(funit=8, seed=21)
+    torch.save(sd, tmp_path / "generator_650.pt")
+    frames = [synth.make_frame(310, 275, seed=30 + k) for k in range(3)]
+    for k, fr in enumerate(frames):
+        imgcodec.write_tiff(str(tmp_path / f"in{k}.tif"), np.ascontiguousarray(fr.transpose(1, 2, 0)))
+    sock = str(tmp_path / "w.sock")
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    worker = subprocess.Popen([sys.executable, "-m", "nind_denoise_amd.serve", "--socket", sock], env=env, cwd=root,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        t0 = time.time()
+        while not os.path.exists(sock):
+            assert worker.poll() is None, worker.stdout.read()
+            assert time.time() - t0 < 180, "worker did not come up"
+            time.sleep(0.1)
+        # the client must not import torch or the HIP library: -X importtime lists every import of the process
+        base = [sys.executable, "-X", "importtime", "-m", "nind_denoise_amd.denoise_image", "--network", "UtNet", "--model_path", "generator_650.pt",
+                "--model_parameters", "funit=8", "--cs", "120", "--ucs", "88", "-ol", "16", "--exif_method", "noexif"]
+        for k in range(3):
+            r = subprocess.run(base + ["--input", f"in{k}.tif", "--output", f"out{k}.tiff", "--server", sock], env=env, cwd=tmp_path,
+                               capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stdout + r.stderr
+            assert "Elapsed time: " in r.stdout and f"Wrote denoised image to {tmp_path}/out{k}.tiff" in r.stdout
+            assert "| torch" not in r.stderr and "numpy" not in r.stderr and "ctypes" not in r.stderr, "client imported heavy modules"
+        # environment variable instead of the flag; an invalid tile size comes back as the CLI's own message and status
+        r = subprocess.run(base[:1] + base[3:-8] + ["--cs", "128", "--ucs", "88", "--input", "in0.tif", "--output", "bad.tiff"],
+                           env=dict(env, NIND_DENOISE_SERVER=sock), cwd=tmp_path, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 1 and "not a valid UtNet tile size" in r.stderr and not os.path.exists(tmp_path / "bad.tiff")
+        r = subprocess.run([sys.executable, "-m", "nind_denoise_amd.client", "--server", sock, "--ping"], env=env, cwd=tmp_path,
+                           capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0 and "4 request(s) served, 1 model(s) resident" in r.stdout, r.stdout + r.stderr
+        r = subprocess.run([sys.executable, "-m", "nind_denoise_amd.client", "--server", sock, "--shutdown"], env=env, cwd=tmp_path,
+                           capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0
+        assert worker.wait(timeout=60) == 0
+    finally:
+        if worker.poll() is None:
+            worker.kill()
+
+    def model_fn(x):
+        with torch.no_grad():
+            return onet.utnet_forward(sd, torch.from_numpy(x)).numpy()
+
+    for k, fr in enumerate(frames):
+        got = np_imgops.img_path_to_np_flt(str(tmp_path / f"out{k}.tiff"))
+        ref = otiler.denoise_frame(fr, 120, 88, 16, model_fn, batch=8)
+        assert_close(torch.from_numpy(got), torch.from_numpy(ref), f"worker image {k}")
+
+
 def test_cli_debug_crop_dumps(dev, tmp_path, monkeypatch):
     # --debug (denoise_image.py:149-150, 260-269): per-tile crop dumps in ./dbg and the last tile with borders; the canvas is the
     # same as without the flag
@@ -1334,6 +1396,90 @@ def test_sharded_frame_with_hip_compute(dev, world):
         assert np.array_equal(got, ref)
     else:
         assert np.abs(got - ref).max() <= 1e-6 and (got == ref).mean() > 0.7
+
+
+def _stream_worker(rank, world, port, geom, funit, n_frames, outq):
+    import torch.distributed as tdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from nind_denoise_amd import dist as ndist
+    from nind_denoise_amd import pipeline
+    from nind_denoise_amd.networks.UtNet import UtNet
+    shared = torch.cuda.device_count() < world
+    d = torch.device("cuda", 0 if shared else rank)
+    torch.cuda.set_device(d)
+    if shared:
+        tdist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        tdist.init_process_group("nccl", rank=rank, world_size=world, device_id=d)
+    try:
+        W, H, cs, ucs, ol, seed = geom
+        # rank 0 owns the model: the other ranks start from other weights and get the raw parameters by broadcast
+        net = UtNet(funit=funit)
+        net.load_state_dict(synth.make_utnet_state_dict(funit=funit, seed=9 if rank == 0 else 77 + rank))
+        net = net.eval().to(d)
+        net.split_k = False
+        ndist.broadcast_parameters(net, src=0)
+        geo = ndist.Geo(W, H, cs, ucs, ol)
+
+        def compute(fr, cv, lo, hi):
+            pipeline.denoise_frame(net, fr, cs, ucs, ol, batch=7, tile_range=(lo, hi), canvas=cv)
+
+        stream = ndist.ShardedFrameStream(compute, geo, d)
+        if stream.frames is not None:
+            for f in stream.frames:
+                f.fill_(float("nan"))       # rows that are never received must never be read
+        for c in stream.canvas:
+            c.fill_(7.0)
+        frames = (torch.from_numpy(synth.make_frame(W, H, seed=seed + k)).to(d) for k in range(n_frames)) if rank == 0 else None
+        got = {}
+        for k, cv in stream.run(frames, n_frames):
+            if rank == 0:
+                got[k] = cv.cpu().numpy()       # (stream-ordered copy of a ring slot)
+        torch.cuda.synchronize()
+        if rank == 0:
+            outq.put(got)
+    finally:
+        tdist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_pipelined_frame_stream_with_hip_compute(dev, world):
+    """dist.ShardedFrameStream (the default N > 1 mode of bench.py) with the device loop as the per-rank compute, 5 frames through
+    the two-slot rings (>= 3 in flight), weights broadcast from rank 0 as raw parameters: world size 1 over RCCL, world size 2
+    over RCCL when two GPUs are visible, else both ranks on GPU 0 over gloo.  Every canvas == the single-GPU canvas of its frame."""
+    import socket
+    import torch.multiprocessing as mp
+    from nind_denoise_amd import pipeline
+    from nind_denoise_amd.networks.UtNet import UtNet
+    geom = (500, 430, 120, 88, 16, 3)
+    funit, n_frames = 16, 5
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_stream_worker, args=(r, world, port, geom, funit, n_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    W, H, cs, ucs, ol, seed = geom
+    net = UtNet(funit=funit)
+    net.load_state_dict(synth.make_utnet_state_dict(funit=funit, seed=9))
+    net = net.eval().to(dev)
+    net.split_k = False
+    assert sorted(got) == list(range(n_frames))
+    for k in range(n_frames):
+        ref = pipeline.denoise_frame(net, torch.from_numpy(synth.make_frame(W, H, seed=seed + k)).to(dev), cs, ucs, ol, batch=7).cpu().numpy()
+        assert np.isfinite(got[k]).all()
+        if world == 1:
+            assert np.array_equal(got[k], ref)
+        else:
+            assert np.abs(got[k] - ref).max() <= 1e-6 and (got[k] == ref).mean() > 0.7
 
 
 # ---------------------------------------------------------------------------- fixtures executed by the reference itself

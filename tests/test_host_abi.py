@@ -280,3 +280,41 @@ def test_useful_regions_equal_receptive_field_backprojection(cs, ucs):
         else:
             assert got == (0, 0, 0, 0), (name, got)           # encoder, pools and fully needed decoder layers: whole tensors
     assert n == restricted
+
+
+def test_thin_client_protocol(tmp_path):
+    """nind_denoise_amd.client against a stand-in worker (no GPU): argument list and working directory go over the Unix socket,
+    streamed output is relayed to the right stream, the exit status is the worker's; the client process imports neither torch
+    nor the HIP library; no worker -> a clear message and a non-zero status."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    import threading
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sock = str(tmp_path / "s.sock")
+    srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    srv.bind(sock)
+    srv.listen(4)
+    seen = []
+
+    def serve():
+        conn, _ = srv.accept()
+        with conn, conn.makefile("rwb") as f:
+            seen.append(json.loads(f.readline()))
+            for m in ({"stream": "stdout", "data": "0/2\n"}, {"stream": "stderr", "data": "warn\n"}, {"stream": "stdout", "data": "done\n"}, {"exit": 7}):
+                f.write((json.dumps(m) + "\n").encode())
+            f.flush()
+    t = threading.Thread(target=serve, daemon=True)
+    t.start()
+    env = dict(os.environ, PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-X", "importtime", "-m", "nind_denoise_amd.denoise_image", "-i", "a.tif", "--server", sock, "-o", "b.tiff"],
+                       env=env, cwd=tmp_path, capture_output=True, text=True, timeout=60)
+    t.join(timeout=10)
+    srv.close()
+    assert r.returncode == 7 and r.stdout == "0/2\ndone\n" and "warn" in r.stderr
+    assert seen == [{"argv": ["-i", "a.tif", "-o", "b.tiff"], "cwd": str(tmp_path)}]
+    assert "| torch" not in r.stderr and "numpy" not in r.stderr and "ctypes" not in r.stderr
+    r = subprocess.run([sys.executable, "-m", "nind_denoise_amd.denoise_image", "-i", "a.tif"], env=dict(env, NIND_DENOISE_SERVER=str(tmp_path / "none.sock")),
+                       cwd=tmp_path, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 111 and "no worker at" in r.stderr
