@@ -222,6 +222,29 @@ int nd_utnet_train_workspace_init(void *workspace, size_t workspace_bytes, int f
 int nd_utnet_train_step(int funit, int flags, const float *params, float *grads, void *blobs, const float *x_nchw,
                         const float *target_nchw, float *y_out_nchw, float w_l1, float w_mse, float w_ssim, float w_msssim,
                         float *loss_out, int batch, int cs, int loss_cs, void *workspace, size_t workspace_bytes, void *stream);
+/* The two halves of the step for torch.autograd, so that the reference's own training statements
+ * (nn_common.py:198-218: `self.model(noisy_batch).clip(0,1)`, `loss.backward()`) run unchanged on the module:
+ * nd_utnet_train_forward = device-side weight packing + forward with the pre-activations kept in `workspace`;
+ * nd_utnet_train_backward = the whole backward from gy = d loss / d output [batch,3,cs,cs] into the flat gradient buffer.
+ * act: ND_ACT_PRELU | ND_ACT_ELU | ND_ACT_HARDSWISH (networks/UtNet.py:17-26; tensors of the parameter layout that the
+ * activation does not have -- PReLU slopes -- are ignored and their gradients left untouched).  `workspace` and `blobs`
+ * carry the forward's state to the backward call: nothing else may use them in between.  The gradient of the input image
+ * is not produced. */
+int nd_utnet_train_forward(int funit, int act, int flags, const float *params, void *blobs, const float *x_nchw, float *y_out_nchw,
+                           int batch, int cs, void *workspace, size_t workspace_bytes, void *stream);
+int nd_utnet_train_backward(int funit, int act, int flags, const float *params, float *grads, void *blobs, const float *gy_nchw,
+                            int batch, int cs, void *workspace, size_t workspace_bytes, void *stream, void *const *bucket_events,
+                            int n_events);
+/* Data-parallel training that overlaps the gradient reduction with the backward pass (BASELINE configs[4]): the flat gradient
+ * buffer is cut into nd_utnet_grad_buckets = 9 contiguous ranges, one per decoder / encoder level, numbered in the order the
+ * backward pass completes them; bucket_events[k] (hipEvent_t, nullable array) is recorded on `stream` when bucket k is final,
+ * so a reducer on another stream can all-reduce it under the backward of the shallower levels.  nd_utnet_train_step_ev = the
+ * fused step with those events. */
+int nd_utnet_grad_buckets(int funit, size_t *offsets, size_t *counts, int max);
+int nd_utnet_train_step_ev(int funit, int flags, const float *params, float *grads, void *blobs, const float *x_nchw,
+                           const float *target_nchw, float *y_out_nchw, float w_l1, float w_mse, float w_ssim, float w_msssim,
+                           float *loss_out, int batch, int cs, int loss_cs, void *workspace, size_t workspace_bytes, void *stream,
+                           void *const *bucket_events, int n_events);
 int nd_adam_step(float *params, const float *grads, float *m, float *v, float *vmax, size_t n, float lr, float beta1,
                  float beta2, float eps, int step, int amsgrad, void *stream);
 

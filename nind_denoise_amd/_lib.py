@@ -87,6 +87,13 @@ _SIGNATURES = {
     "nd_utnet_train_workspace_init": (c_int, [c_void_p, c_size_t, c_int, c_int, c_int, c_void_p]),
     "nd_utnet_train_step": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
                                     c_float, c_float, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "nd_utnet_train_forward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "nd_utnet_train_backward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t,
+                                        c_void_p, POINTER(c_void_p), c_int]),
+    "nd_utnet_grad_buckets": (c_int, [c_int, POINTER(c_size_t), POINTER(c_size_t), c_int]),
+    "nd_utnet_train_step_ev": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
+                                       c_float, c_float, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p, POINTER(c_void_p),
+                                       c_int]),
     "nd_adam_step": (c_int, [c_void_p] * 5 + [c_size_t, c_float, c_float, c_float, c_float, c_int, c_int, c_void_p]),
     "nd_ssim_workspace_bytes": (c_size_t, [c_int] * 4),
     "nd_ssim": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_void_p, c_size_t, c_void_p]),

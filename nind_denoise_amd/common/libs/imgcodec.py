@@ -178,7 +178,7 @@ def write_tiff(path, img):
     H, W, _ = img.shape
     bps = img.dtype.itemsize * 8
     sfmt = 3 if img.dtype == np.float32 else 1
-    data = img.astype(img.dtype.newbyteorder("<"), copy=False).tobytes()
+    data = memoryview(np.ascontiguousarray(img.astype(img.dtype.newbyteorder("<"), copy=False))).cast("B")   # (no copy of the samples)
     rps = max(1, min(H, (1 << 20) // max(1, W * 3 * img.dtype.itemsize)))
     nstrips = (H + rps - 1) // rps
     row_bytes = W * 3 * img.dtype.itemsize

@@ -23,10 +23,19 @@ def tensor_to_imgfile(tensor, path):
             arr = tensor.clip(0, 1).mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to('cpu', torch.uint8).numpy()
             Image.fromarray(arr).save(path)
         elif ext in ['.png', '.tif']:
-            nptensor = (tensor.clip(0, 1) * 65535).round().cpu().numpy().astype(np.uint16).transpose(1, 2, 0)
+            if tensor.is_cuda:
+                # same IEEE float32 multiply and round-half-even as on the host, done where the canvas lives; the 16-bit HWC image
+                # (half the bytes of the float canvas) comes down already in file order
+                q = (tensor.clip(0, 1) * 65535).round().to(torch.int32).permute(1, 2, 0).to(torch.int16).contiguous()
+                nptensor = q.cpu().numpy().view(np.uint16)
+            else:
+                nptensor = (tensor.clip(0, 1) * 65535).round().cpu().numpy().astype(np.uint16).transpose(1, 2, 0)
             (imgcodec.write_png if ext == '.png' else imgcodec.write_tiff)(path, nptensor)
         elif ext in ['tiff']:
-            nptensor = tensor.cpu().numpy().astype(np.float32).transpose(1, 2, 0)
+            if tensor.is_cuda:
+                nptensor = tensor.permute(1, 2, 0).contiguous().cpu().numpy()   # (the CHW -> HWC transpose on the GPU)
+            else:
+                nptensor = tensor.cpu().numpy().astype(np.float32).transpose(1, 2, 0)
             imgcodec.write_tiff(path, nptensor)
         else:
             raise NotImplementedError(f'Extension in {path}')

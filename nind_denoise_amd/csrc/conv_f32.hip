@@ -129,9 +129,9 @@ __global__ __launch_bounds__(256) void k_split_finish(ConvParams p, int mblk, in
         int co = m4;
         long pix;
         if (up) {
-            const int ab = m4 / p.cout;
-            co = m4 - ab * p.cout;
-            pix = (long)bi * p.Po + (long)(2 * y + p.opad + (ab >> 1)) * p.Wo + (2 * x + p.opad + (ab & 1));
+            const NdUpRow ur = nd_up_row(m4, p.cout, dt);
+            co = ur.co;
+            pix = (long)bi * p.Po + (long)(2 * y + p.opad + ur.a) * p.Wo + (2 * x + p.opad + ur.b);
         } else {
             pix = (long)bi * p.Po + (long)(y + p.opad) * p.Wo + (x + p.opad);
         }
@@ -367,6 +367,7 @@ int nd_launch_conv(const ConvDesc &d, hipStream_t stream) {
     p.w_bs = (long)d.w_bs;
     if (d.nbatch > 1 && d.pre) ND_FAIL(ND_EINVAL, "conv: a batched launch keeps no pre-activation copy");
     nd_conv_fastdivs(p);
+    if (dt != ND_F32) p.fd_upq = nd_fastdiv(p.cout / 8 > 0 ? p.cout / 8 : 1);   // 8 channels per plane element
     const long ntiles = (long)p.tiles_per_problem * (d.nbatch > 1 ? d.nbatch : 1);
     const int per_cu = lds * 2 <= kMaxLds && V.threads <= 256 ? 2 : 1;
     const long slots = (long)ncus * per_cu;
@@ -378,6 +379,10 @@ int nd_launch_conv(const ConvDesc &d, hipStream_t stream) {
     p.nitems = (int)(sp.first + (ntiles - sp.first) * sp.S);
     p.part = (f32x4 *)d.part;
     const long grid = p.nitems < slots ? p.nitems : slots;
+#ifdef ND_QP_ABLATE
+    static const int abl_env = getenv("ND_QP_ABL") ? atoi(getenv("ND_QP_ABL")) : 0;   // make ABLATE=1: see fill_slice / epilogue
+    p.dbg = abl_env;
+#endif
 #ifdef ND_QP_STAMPS
     static const int dbg_env = getenv("ND_QP_DBG") ? atoi(getenv("ND_QP_DBG")) : 0;
     if (dbg_env & 128) {

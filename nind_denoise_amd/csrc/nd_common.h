@@ -135,6 +135,26 @@ const char *nd_conv_variant_label(int v);
 static inline int nd_mtiles(int kind, int cout) {
     return kind == ND_CONVT2S2 ? (4 * cout + 255) / 256 * 8 : (cout + 127) / 128 * 4;   // up layers use 256-row workgroup tiles
 }
+// Row order of the GEMM of a 2x2 stride-2 transpose (M = 4 * Cout rows; weights and bias are packed in it, the conv epilogue
+// and k_split_finish decode it).  An MFMA accumulator hands lane (pixel j, half h) the rows 8g + 4h + e (e = 0..3) of a 32-row
+// tile.  The order puts the SAME channels of the two horizontally adjacent output pixels (2x, 2x + 1) into the two lane
+// halves, so that a wave's store instruction writes 64 consecutive 16-byte plane elements (1 KiB contiguous) instead of 16-byte
+// pieces at a 32-byte stride:
+//   fp32   (4 channels per plane element):  m = 8 * (a * Cout/4 + quad) + 4 * b + e          co = 4 * quad + e
+//   16-bit (8 channels per plane element):  m = 16 * (a * Cout/8 + oct) + 8 * b + e8         co = 8 * oct + e8
+//          (there the epilogue first exchanges the halves of two 8-row groups, v_permlane32_swap, so that a lane owns all 8
+//           channels of one pixel)
+// (a, b) = output sub-position (row, column) of ConvTranspose2d(2, stride 2): out[2y + a][2x + b].
+struct NdUpRow { int a, b, co; };
+__host__ __device__ static inline NdUpRow nd_up_row(int m, int cout, int dt) {
+    NdUpRow r;
+    const int cpp = dt == ND_F32 ? 4 : 8, q = cout / cpp;
+    const int G = m / (2 * cpp), e = m % cpp;
+    r.b = (m / cpp) & 1;
+    r.a = G / q;
+    r.co = cpp * (G % q) + e;
+    return r;
+}
 static inline int nd_taps(int kind) { return (kind == ND_CONV3 || kind == ND_CONVT3) ? 9 : (kind == ND_CONV2S2 ? 4 : 1); }
 // K block = two planes = the K extent of one ds_read_b128 per operand: 8 fp32 channels or 16 bf16/fp16 channels
 static inline int nd_kblocks(int cin, int dt = ND_F32) { return (cin + 2 * nd_cpp(dt) - 1) / (2 * nd_cpp(dt)); }

@@ -9,7 +9,8 @@
 //                                                                                  channel transpose turn the transpose
 //                                                                                  conv into a correlation on the
 //                                                                                  zero-bordered input)
-//     CONVT2S2 Weff[(a,b,co)][ci]    = w[ci][co][a][b],  m = (2a+b)*Cout + co     (w: [Cin,Cout,2,2])
+//     CONVT2S2 Weff[m][ci]           = w[ci][co][a][b],  (a, b, co) = nd_up_row(m) (w: [Cin,Cout,2,2]; row order chosen for
+//                                                                                  contiguous pixel-shuffle stores, nd_common.h)
 //     CONV1    Weff[co][ci]          = w[co][ci]
 //     CONV2S2  Weff[co][ci][(a,b)]   = w[co][ci][a][b]                           (w: [Cout,Cin,2,2], stride 2)
 // bf16 / fp16: the same order with 8 channels per lane (ci = 16*kb + 8*h + s), values rounded to nearest even.
@@ -57,8 +58,8 @@ void nd_pack_layer(int kind, int cin, int cout, int dt, const float *w, const fl
             case ND_CONV3: return w[((size_t)m * cin + ci) * 9 + t];
             case ND_CONVT3: return w[((size_t)ci * cout + m) * 9 + (8 - t)];
             case ND_CONVT2S2: {
-                const int ab = m / cout, co = m - ab * cout;
-                return w[((size_t)ci * cout + co) * 4 + ab];
+                const NdUpRow r = nd_up_row(m, cout, dt);
+                return w[((size_t)ci * cout + r.co) * 4 + 2 * r.a + r.b];
             }
             case ND_CONV2S2: return w[((size_t)m * cin + ci) * 4 + t];
             default: return w[(size_t)m * cin + ci];
@@ -83,7 +84,7 @@ void nd_pack_layer(int kind, int cin, int cout, int dt, const float *w, const fl
             }
     for (int m = 0; m < MT * 32; ++m) {
         float v = 0.f;
-        if (m < M && bias) v = bias[kind == ND_CONVT2S2 ? m % cout : m];
+        if (m < M && bias) v = bias[kind == ND_CONVT2S2 ? nd_up_row(m, cout, dt).co : m];
         bp[m] = v;
     }
 }

@@ -23,8 +23,8 @@ __global__ void k_pack_dev(int kind, int cin, int cout, int M, int KB, int taps,
                 case ND_CONV3: v = w[((long)m * cin + ci) * 9 + t]; break;
                 case ND_CONVT3: v = w[((long)ci * cout + m) * 9 + (8 - t)]; break;
                 case ND_CONVT2S2: {
-                    const int ab = m / cout, co = m - ab * cout;
-                    v = w[((long)ci * cout + co) * 4 + ab];
+                    const NdUpRow r = nd_up_row(m, cout, ND_F32);
+                    v = w[((long)ci * cout + r.co) * 4 + 2 * r.a + r.b];
                     break;
                 }
                 case ND_CONV2S2: v = w[((long)m * cin + ci) * 4 + t]; break;
@@ -34,7 +34,7 @@ __global__ void k_pack_dev(int kind, int cin, int cout, int M, int KB, int taps,
         packed[idx] = v;
     } else if (idx < nw + nb) {
         const int m = (int)(idx - nw);
-        packed[idx] = (m < M && bias) ? bias[kind == ND_CONVT2S2 ? m % cout : m] : 0.f;
+        packed[idx] = (m < M && bias) ? bias[kind == ND_CONVT2S2 ? nd_up_row(m, cout, ND_F32).co : m] : 0.f;
     }
 }
 

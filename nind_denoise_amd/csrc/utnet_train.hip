@@ -27,13 +27,16 @@ int nd_launch_wgrad(const QpBuf &A, int a_plane0, int M, const QpBuf &Bq, int b_
 int nd_launch_channel_sum(const QpBuf &src, int plane0, int C, float *out, float *scratch, hipStream_t s);
 
 // ------------------------------------------------------------------ elementwise kernels
-// g (interior of a bordered gradient buffer, planes [plane0, plane0+planes)) *= prelu'(pre);  partial[block] = sum g*pre over pre <= 0
-__global__ __launch_bounds__(256) void k_prelu_bwd(f32x4 *__restrict__ g, long gnp, int gHb, int gWb, int gpad,
-                                                   const f32x4 *__restrict__ pre, long pnp, int H, int W,
-                                                   const float *__restrict__ slope, float *__restrict__ partial) {
+// g (interior of a bordered gradient buffer, planes [plane0, plane0+planes)) *= act'(pre), pre = conv output + bias;
+// PReLU also: partial[block] = sum g*pre over pre <= 0 (the slope's gradient).  ELU: act' = 1 | exp(pre); Hardswish: 0 | (2 pre + 3) / 6 | 1
+// (torch's derivative at the break points: ELU'(0) = 1 from the exp branch, Hardswish' = 0 at -3 and 1 at +3 are not reached by (2x+3)/6 -- see below)
+template <int ACT>
+__global__ __launch_bounds__(256) void k_act_bwd(f32x4 *__restrict__ g, long gnp, int gHb, int gWb, int gpad,
+                                                 const f32x4 *__restrict__ pre, long pnp, int H, int W,
+                                                 const float *__restrict__ slope, float *__restrict__ partial) {
     __shared__ float red[256];
     const int b = blockIdx.x, q = blockIdx.y;
-    const float a = *slope;
+    const float a = ACT == ND_ACT_PRELU ? *slope : 0.f;
     float acc = 0.f;
     for (int i = threadIdx.x; i < H * W; i += 256) {
         const int y = i / W, x = i - y * W;
@@ -42,13 +45,21 @@ __global__ __launch_bounds__(256) void k_prelu_bwd(f32x4 *__restrict__ g, long g
         f32x4 gv = *gp;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            if (!(pv[e] > 0.f)) {
-                acc += gv[e] * pv[e];
-                gv[e] *= a;
+            if (ACT == ND_ACT_PRELU) {
+                if (!(pv[e] > 0.f)) {
+                    acc += gv[e] * pv[e];
+                    gv[e] *= a;
+                }
+            } else if (ACT == ND_ACT_ELU) {
+                if (!(pv[e] > 0.f)) gv[e] *= expf(pv[e]);                     // torch: grad * (x <= 0 ? alpha * exp(x) : 1), alpha = 1
+            } else {
+                // torch hardswish_backward: x < -3 -> 0;  x <= 3 -> grad * (x / 3 + 0.5);  else grad
+                gv[e] = pv[e] < -3.f ? 0.f : (pv[e] <= 3.f ? gv[e] * (pv[e] / 3.f + 0.5f) : gv[e]);
             }
         }
         *gp = gv;
     }
+    if (ACT != ND_ACT_PRELU) return;
     red[threadIdx.x] = acc;
     __syncthreads();
     for (int k = 128; k > 0; k >>= 1) {
@@ -276,6 +287,27 @@ ParamLayout param_layout(int f) {
     pl.total = o;
     return pl;
 }
+// Gradient buckets for a data-parallel reduction that overlaps the backward pass: one per decoder / encoder level, numbered in
+// the order the backward pass COMPLETES them (0: up4 + tconvs4, 1: up3 + tconvs3, 2: up2 + tconvs2, 3: up1 + tconvs1, 4: bottom,
+// 5: convs4, 6: convs3, 7: convs2, 8: convs1).  Each is one contiguous range of the flat state-dict-order buffer.
+constexpr int kNumBuckets = 9;
+int bucket_of_key(const std::string &key) {
+    static const char *const prefix[kNumBuckets][2] = {{"tconvs4", "up4"}, {"tconvs3", "up3"}, {"tconvs2", "up2"}, {"tconvs1", "up1"},
+                                                        {"bottom", "bottom"}, {"convs4", "convs4"}, {"convs3", "convs3"},
+                                                        {"convs2", "convs2"}, {"convs1", "convs1"}};
+    for (int k = 0; k < kNumBuckets; ++k)
+        for (int j = 0; j < 2; ++j) {
+            const std::string p = prefix[k][j];
+            if (key.compare(0, p.size(), p) == 0 && (key.size() == p.size() || key[p.size()] == '.')) return k;
+        }
+    return -1;
+}
+// the layer whose gradients finish a bucket: the bucket's first layer in forward order
+int bucket_tail_layer(int k) {
+    for (int i = 0; i < kNumLayers; ++i)
+        if (bucket_of_key(kLayers[i].key) == k) return i;
+    return -1;
+}
 // name of the PReLU tensor that follows layer `key` in its Sequential
 std::string prelu_name(const char *key) {
     std::string k(key);
@@ -462,132 +494,123 @@ extern "C" int nd_utnet_train_workspace_init(void *ws, size_t ws_bytes, int funi
     return ND_OK;
 }
 
-// One training step without the optimizer: packs the weights on the device, runs forward (PReLU only), the loss
-//   loss = w_l1 * mean|g - target| + w_mse * mean (g - target)^2 + w_ssim * mean_n(1 - SSIM_n(g, target))
-//          + w_msssim * mean_n(1 - MS-SSIM_n(g, target)),      g = clip(y, 0, 1)          (nn_common.py:198-199, 226-241)
-// and the backward pass.  params / grads: flat fp32 buffers in state-dict order (nd_utnet_param_range);
-// x, target, y_out: [batch,3,cs,cs] NCHW fp32; loss_out: one float in HBM; blobs: nd_utnet_train_blob_bytes scratch.
-extern "C" int nd_utnet_train_step(int funit, int flags, const float *params, float *grads, void *blobs, const float *x,
-                                   const float *target, float *y_out, float w_l1, float w_mse, float w_ssim, float w_msssim,
-                                   float *loss_out, int batch, int cs, int loss_cs, void *ws, size_t ws_bytes, void *stream) {
+// ---- the step in two halves: (1) weight packing + forward with the pre-activations kept, (2) backward from d loss / d output.
+// nd_utnet_train_step runs both with the loss between them; nd_utnet_train_forward / nd_utnet_train_backward expose the halves
+// to torch.autograd (networks/UtNet.py: model(x).clip(0, 1), loss.backward() of nn_common.py:198-218 then work unchanged).
+struct TrainCtx {
+    int f, B, cs, flags, act;
+    TrainPlan t;
+    ParamLayout pl;
+    BlobLayout bl;
+    BwdBlob bb;
+    float *fblob, *bblob;
+    unsigned char fwd_w1[kNumLayers], bwd_w1[kNumLayers];
+    const float *slopes[kNumSlopes];
+    hipStream_t s;
+};
+
+static int train_ctx(TrainCtx &c, int funit, int flags, int act, const float *params, void *blobs, int batch, int cs, void *ws,
+                     size_t ws_bytes, void *stream) {
     ND_TRY(nd_check_flags(flags));
     ND_TRY(check_train(funit, cs, batch));
-    const int L = loss_cs > 0 ? loss_cs : cs;   // the criteria see the centre crop of this size (nn_train.py:319-323)
-    if (L > cs) ND_FAIL(ND_EINVAL, "UtNet training: loss_cs=%d exceeds the crop size %d", L, cs);
-    if (w_msssim != 0.f && L < 161)
-        ND_FAIL(ND_EINVAL, "UtNet training: the MS-SSIM loss needs crops of at least 161 pixels (five scales of an 11-tap window), "
-                           "got %d; the reference fails on them too (pt_losses.py:20-28)", L);
-    if (w_ssim != 0.f && L < 11) ND_FAIL(ND_EINVAL, "UtNet training: the SSIM loss needs at least 11 pixels, got %d", L);
-    if (!params || !grads || !blobs || !x || !target || !y_out || !loss_out || !ws) ND_FAIL(ND_EINVAL, "train step: null pointer");
-    TrainPlan t = make_train_plan(funit, cs, batch, (char *)ws);
-    if (ws_bytes < t.bytes) ND_FAIL(ND_ENOMEM, "UtNet training workspace: %zu B given, %zu B needed", ws_bytes, t.bytes);
-    hipStream_t s = (hipStream_t)stream;
-    const int f = funit, B = batch;
-    const ParamLayout pl = param_layout(f);
-    const BlobLayout bl = blob_layout(f, ND_F32, false, true);
+    if (act < ND_ACT_PRELU || act > ND_ACT_HARDSWISH) ND_FAIL(ND_EINVAL, "UtNet training: unknown activation %d", act);
+    if (!params || !blobs || !ws) ND_FAIL(ND_EINVAL, "train step: null pointer");
+    c.f = funit;
+    c.B = batch;
+    c.cs = cs;
+    c.flags = flags;
+    c.act = act;
+    c.t = make_train_plan(funit, cs, batch, (char *)ws);
+    if (ws_bytes < c.t.bytes) ND_FAIL(ND_ENOMEM, "UtNet training workspace: %zu B given, %zu B needed", ws_bytes, c.t.bytes);
+    c.s = (hipStream_t)stream;
+    c.pl = param_layout(funit);
+    c.bl = blob_layout(funit, ND_F32, false, true);
     // 3x3 layers whose rows fit its LDS images run the fused 1-D Winograd kernel, forward and data gradient (else the direct one)
-    unsigned char fwd_w1[kNumLayers] = {}, bwd_w1[kNumLayers] = {};
+    memset(c.fwd_w1, 0, sizeof(c.fwd_w1));
+    memset(c.bwd_w1, 0, sizeof(c.bwd_w1));
     for (const Step &st : kSteps) {
         if (st.layer < 0) continue;
         const LayerSpec &l = kLayers[st.layer];
         if (l.kind != ND_CONV3 && l.kind != ND_CONVT3) continue;
         if (!(flags & ND_FLAG_DIRECT_CONV)) {
-            fwd_w1[st.layer] = nd_w1d_fits(kW1dTile, t.fwd.buf[st.src]);
-            bwd_w1[st.layer] = st.layer > 0 && nd_w1d_fits(kW1dTile, t.g[st.dst]);
+            c.fwd_w1[st.layer] = nd_w1d_fits(kW1dTile, c.t.fwd.buf[st.src]);
+            c.bwd_w1[st.layer] = st.layer > 0 && nd_w1d_fits(kW1dTile, c.t.g[st.dst]);
         }
     }
-    const BwdBlob bb = bwd_blob_layout(f);
-    float *fblob = (float *)blobs;
-    float *bblob = fblob + bl.total;
-    auto P = [&](const std::string &name) -> const float * { return params + pl.off[tensor_index(name)]; };
-    auto G = [&](const std::string &name) -> float * { return grads + pl.off[tensor_index(name)]; };
+    c.bb = bwd_blob_layout(funit);
+    c.fblob = (float *)blobs;
+    c.bblob = c.fblob + c.bl.total;
+    for (int k = 0; k < kNumSlopes; ++k) c.slopes[k] = nullptr;
+    for (int i = 0; i < kNumLayers; ++i)
+        if (kLayers[i].prelu >= 0) c.slopes[kLayers[i].prelu] = params + c.pl.off[tensor_index(prelu_name(kLayers[i].key))];
+    return ND_OK;
+}
 
-    // ---- 1. pack weights on the device (forward roles, and transposed roles for the data gradients)
-    const float *slopes[kNumSlopes] = {};
+// (1) pack the weights on the device (forward roles, and transposed roles for the data gradients), forward with the
+// pre-activations kept; y_out: [batch,3,cs,cs]
+static int train_forward(TrainCtx &c, const float *params, const float *x, float *y_out) {
+    const int f = c.f, B = c.B, cs = c.cs;
+    hipStream_t s = c.s;
+    const BlobLayout &bl = c.bl;
+    const BwdBlob &bb = c.bb;
+    float *fblob = c.fblob, *bblob = c.bblob;
+    auto P = [&](const std::string &name) -> const float * { return params + c.pl.off[tensor_index(name)]; };
     for (int i = 0; i < kNumLayers; ++i) {
         const LayerSpec &l = kLayers[i];
         const int ci = lcin(l, f), co = lcout(l, f);
         const float *w = P(std::string(l.key) + ".weight"), *b = P(std::string(l.key) + ".bias");
-        if (l.prelu >= 0) slopes[l.prelu] = P(prelu_name(l.key));
         if (l.kind == ND_CONV1) {
             ND_HIP(hipMemcpyAsync(fblob + bl.off[i], w, sizeof(float) * 3 * ci, hipMemcpyDeviceToDevice, s));
             ND_HIP(hipMemcpyAsync(fblob + bl.off[i] + 3 * ci, b, sizeof(float) * 3, hipMemcpyDeviceToDevice, s));
             continue;
         }
-        {
-            const int MT = nd_mtiles(l.kind, co), KB = nd_kblocks(ci), taps = nd_taps(l.kind);
-            const int M = l.kind == ND_CONVT2S2 ? 4 * co : co;
-            (void)MT; (void)KB; (void)taps; (void)M;
-            if (fwd_w1[i])
-                nd_pack_w1d_device(kW1dTile, l.kind, ci, co, w, b, fblob + bl.off[i], s);
-            else
-                nd_pack_layer_device(l.kind, ci, co, w, b, fblob + bl.off[i], s);
-        }
+        if (c.fwd_w1[i])
+            nd_pack_w1d_device(kW1dTile, l.kind, ci, co, w, b, fblob + bl.off[i], s);
+        else
+            nd_pack_layer_device(l.kind, ci, co, w, b, fblob + bl.off[i], s);
         if (i > 0) {   // transposed role: cin' = co, cout' = ci, no bias
             const int kt = transposed_kind(l.kind);
-            const int MT = nd_mtiles(kt, ci), KB = nd_kblocks(co), taps = nd_taps(kt);
-            (void)MT; (void)KB; (void)taps;
-            if (bwd_w1[i])
+            if (c.bwd_w1[i])
                 nd_pack_w1d_device(kW1dTile, kt, co, ci, w, nullptr, bblob + bb.off[i], s);
             else
                 nd_pack_layer_device(kt, co, ci, w, nullptr, bblob + bb.off[i], s);
         }
     }
     ND_HIP(hipGetLastError());
-    // slope table of the forward blob header
-    for (int k = 0; k < kNumSlopes; ++k)
-        ND_HIP(hipMemcpyAsync(fblob + k, slopes[k], sizeof(float), hipMemcpyDeviceToDevice, s));
-
-    // ---- 2. forward (training mode: pre-activations kept)
-    ND_TRY(nd_launch_reflect_pack(x, B, cs, cs, t.fwd.buf[X0], s));
-    ND_TRY(run_stack(f, ND_ACT_PRELU, ND_F32, fblob, t.fwd, s, flags, nullptr, t.pre, nullptr, fwd_w1));
+    // slope table of the forward blob header (PReLU only: the other activations have no parameters)
+    if (c.act == ND_ACT_PRELU)
+        for (int k = 0; k < kNumSlopes; ++k)
+            ND_HIP(hipMemcpyAsync(fblob + k, c.slopes[k], sizeof(float), hipMemcpyDeviceToDevice, s));
+    ND_TRY(nd_launch_reflect_pack(x, B, cs, cs, c.t.fwd.buf[X0], s));
+    ND_TRY(run_stack(f, c.act, ND_F32, fblob, c.t.fwd, s, c.flags, nullptr, c.t.pre, nullptr, c.fwd_w1));
     const float *fw = fblob + bl.off[kNumLayers - 1];
-    ND_TRY(nd_launch_final1x1(t.fwd.buf[T4B], f, fw, fw + 3 * f, 2, y_out, cs, cs, s));
+    ND_TRY(nd_launch_final1x1(c.t.fwd.buf[T4B], f, fw, fw + 3 * f, 2, y_out, cs, cs, s));
+    return ND_OK;
+}
 
-    // ---- 3. loss and its gradient, on the centre crop of loss_cs pixels (the whole output when loss_cs == cs)
-    const long nfull = (long)B * 3 * cs * cs, nout = (long)B * 3 * L * L;
-    const int lblocks = 1024;
-    const float *yl = y_out, *tl = target;
-    float *gl = t.gy;
-    if (L != cs) {
-        hipLaunchKernelGGL(k_center_crop, dim3(1024), dim3(256), 0, s, (const float *)y_out, cs, L, nout, t.ycrop);
-        hipLaunchKernelGGL(k_center_crop, dim3(1024), dim3(256), 0, s, target, cs, L, nout, t.tcrop);
-        yl = t.ycrop;
-        tl = t.tcrop;
-        gl = t.gcrop;
-    }
-    hipLaunchKernelGGL(k_loss_grad, dim3(lblocks), dim3(256), 0, s, yl, tl, nout, w_l1, w_mse, gl, t.red);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, (const float *)t.red, lblocks, 1.f / (float)nout, loss_out);
-    ND_HIP(hipGetLastError());
-    if (w_ssim != 0.f || w_msssim != 0.f) {
-        hipLaunchKernelGGL(k_clip01, dim3(1024), dim3(256), 0, s, yl, nout, t.yclip);
-        int acc = 0;
-        if (w_ssim != 0.f) {
-            ND_TRY(nd_ssim_loss_grad(t.yclip, tl, B, 3, L, L, 0, w_ssim, loss_out, t.gssim, acc, t.ssim_ws, t.ssim_ws_bytes, s));
-            acc = 1;
-        }
-        if (w_msssim != 0.f)
-            ND_TRY(nd_ssim_loss_grad(t.yclip, tl, B, 3, L, L, 1, w_msssim, loss_out, t.gssim, acc, t.ssim_ws, t.ssim_ws_bytes, s));
-        hipLaunchKernelGGL(k_add_clip_grad, dim3(1024), dim3(256), 0, s, yl, (const float *)t.gssim, nout, gl);
-        ND_HIP(hipGetLastError());
-    }
-    if (L != cs) {
-        hipLaunchKernelGGL(k_center_uncrop, dim3(1024), dim3(256), 0, s, (const float *)t.gcrop, cs, L, nfull, t.gy);
-        ND_HIP(hipGetLastError());
-    }
-
+// (2) backward: gy = d loss / d output [batch,3,cs,cs]; every parameter gradient into the flat buffer `grads`
+static int train_backward(TrainCtx &c, float *grads, const float *gy, void *const *bucket_ev = nullptr) {
+    const int f = c.f, B = c.B, cs = c.cs, flags = c.flags;
+    hipStream_t s = c.s;
+    TrainPlan &t = c.t;
+    const BlobLayout &bl = c.bl;
+    const BwdBlob &bb = c.bb;
+    float *fblob = c.fblob, *bblob = c.bblob;
+    const float *const *slopes = c.slopes;
+    auto G = [&](const std::string &name) -> float * { return grads + c.pl.off[tensor_index(name)]; };
+    const float *fw = fblob + bl.off[kNumLayers - 1];
     // ---- 4. backward
     // final 1x1
     {
         const QpBuf &a = t.fwd.buf[T4B], &g = t.g[T4B];
         f32x4 *pw = (f32x4 *)t.red;
         float *pb = t.red + (size_t)4 * 3 * (f / 4) * B;
-        hipLaunchKernelGGL(k_final_wgrad1, dim3(3, f / 4, B), dim3(256), 0, s, (const float *)t.gy, cs, (const f32x4 *)a.base,
+        hipLaunchKernelGGL(k_final_wgrad1, dim3(3, f / 4, B), dim3(256), 0, s, gy, cs, (const f32x4 *)a.base,
                            a.np(), a.Hb, a.Wb, 2, pw, pb);
         hipLaunchKernelGGL(k_final_wgrad2, dim3(3, f / 4), dim3(64), 0, s, (const f32x4 *)pw, (const float *)pb, f / 4, B, f,
                            G("tconvs4.4.weight"), G("tconvs4.4.bias"));
         dim3 grid((g.Wb + 127) / 128, g.Hb, B * (f / 4));
-        hipLaunchKernelGGL(k_final_bwd_data, grid, dim3(128), 0, s, (const float *)t.gy, cs, fw, f, 2, (f32x4 *)g.base, g.np(), g.Hb,
+        hipLaunchKernelGGL(k_final_bwd_data, grid, dim3(128), 0, s, gy, cs, fw, f, 2, (f32x4 *)g.base, g.np(), g.Hb,
                            g.Wb, B);
         ND_HIP(hipGetLastError());
     }
@@ -615,9 +638,18 @@ extern "C" int nd_utnet_train_step(int funit, int flags, const float *params, fl
         // activation backward (in place) + slope gradient
         if (l.prelu >= 0) {
             const QpBuf &pr = t.pre[l.prelu];
-            hipLaunchKernelGGL(k_prelu_bwd, dim3(B, oplanes), dim3(256), 0, s, (f32x4 *)go.base + (long)oplane0 * go.np(), go.np(),
-                               go.Hb, go.Wb, go.pad, (const f32x4 *)pr.base, pr.np(), oh, ow, slopes[l.prelu], t.red);
-            hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, (const float *)t.red, B * oplanes, 1.f, G(prelu_name(l.key)));
+            f32x4 *gq = (f32x4 *)go.base + (long)oplane0 * go.np();
+            if (c.act == ND_ACT_PRELU) {
+                hipLaunchKernelGGL(k_act_bwd<ND_ACT_PRELU>, dim3(B, oplanes), dim3(256), 0, s, gq, go.np(), go.Hb, go.Wb, go.pad,
+                                   (const f32x4 *)pr.base, pr.np(), oh, ow, slopes[l.prelu], t.red);
+                hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, (const float *)t.red, B * oplanes, 1.f, G(prelu_name(l.key)));
+            } else if (c.act == ND_ACT_ELU) {
+                hipLaunchKernelGGL(k_act_bwd<ND_ACT_ELU>, dim3(B, oplanes), dim3(256), 0, s, gq, go.np(), go.Hb, go.Wb, go.pad,
+                                   (const f32x4 *)pr.base, pr.np(), oh, ow, (const float *)nullptr, t.red);
+            } else {
+                hipLaunchKernelGGL(k_act_bwd<ND_ACT_HARDSWISH>, dim3(B, oplanes), dim3(256), 0, s, gq, go.np(), go.Hb, go.Wb, go.pad,
+                                   (const f32x4 *)pr.base, pr.np(), oh, ow, (const float *)nullptr, t.red);
+            }
             ND_HIP(hipGetLastError());
         }
         // bias gradient
@@ -659,7 +691,7 @@ extern "C" int nd_utnet_train_step(int funit, int flags, const float *params, fl
             d.part = t.fwd.split;
             d.part_bytes = kSplitScratchBytes;
             d.nosplit = (flags & ND_FLAG_NO_SPLITK) != 0;
-            if (bwd_w1[st.layer]) {
+            if (c.bwd_w1[st.layer]) {
                 d.bias = d.wpk + (size_t)nd_mtiles(ND_CONV3, ci) * nd_kblocks(co) * 18 * 256;
                 // (a data gradient keeps no pre-activation copy: the inference form with the LDS-shared transform applies)
                 if (nd_w2d_ok(d.in) && !(flags & ND_FLAG_W1D_REGS))
@@ -670,8 +702,126 @@ extern "C" int nd_utnet_train_step(int funit, int flags, const float *params, fl
                 ND_TRY(nd_launch_conv(d, s));
             }
         }
+        // every parameter gradient of this layer's level is final once the level's first layer is done: tell the reducer
+        if (bucket_ev) {
+            const int k = bucket_of_key(l.key);
+            if (k >= 0 && bucket_tail_layer(k) == st.layer) ND_HIP(hipEventRecord((hipEvent_t)bucket_ev[k], s));
+        }
     }
     return ND_OK;
+}
+
+// One training step without the optimizer: packs the weights on the device, runs forward (PReLU only), the loss
+//   loss = w_l1 * mean|g - target| + w_mse * mean (g - target)^2 + w_ssim * mean_n(1 - SSIM_n(g, target))
+//          + w_msssim * mean_n(1 - MS-SSIM_n(g, target)),      g = clip(y, 0, 1)          (nn_common.py:198-199, 226-241)
+// and the backward pass.  params / grads: flat fp32 buffers in state-dict order (nd_utnet_param_range);
+// x, target, y_out: [batch,3,cs,cs] NCHW fp32; loss_out: one float in HBM; blobs: nd_utnet_train_blob_bytes scratch.
+static int train_step_impl(int funit, int flags, const float *params, float *grads, void *blobs, const float *x,
+                           const float *target, float *y_out, float w_l1, float w_mse, float w_ssim, float w_msssim,
+                           float *loss_out, int batch, int cs, int loss_cs, void *ws, size_t ws_bytes, void *stream,
+                           void *const *bucket_ev) {
+    const int L = loss_cs > 0 ? loss_cs : cs;   // the criteria see the centre crop of this size (nn_train.py:319-323)
+    if (L > cs) ND_FAIL(ND_EINVAL, "UtNet training: loss_cs=%d exceeds the crop size %d", L, cs);
+    if (w_msssim != 0.f && L < 161)
+        ND_FAIL(ND_EINVAL, "UtNet training: the MS-SSIM loss needs crops of at least 161 pixels (five scales of an 11-tap window), "
+                           "got %d; the reference fails on them too (pt_losses.py:20-28)", L);
+    if (w_ssim != 0.f && L < 11) ND_FAIL(ND_EINVAL, "UtNet training: the SSIM loss needs at least 11 pixels, got %d", L);
+    if (!grads || !x || !target || !y_out || !loss_out) ND_FAIL(ND_EINVAL, "train step: null pointer");
+    TrainCtx c;
+    ND_TRY(train_ctx(c, funit, flags, ND_ACT_PRELU, params, blobs, batch, cs, ws, ws_bytes, stream));
+    ND_TRY(train_forward(c, params, x, y_out));
+    TrainPlan &t = c.t;
+    hipStream_t s = c.s;
+    const int B = batch;
+    // ---- 3. loss and its gradient, on the centre crop of loss_cs pixels (the whole output when loss_cs == cs)
+    const long nfull = (long)B * 3 * cs * cs, nout = (long)B * 3 * L * L;
+    const int lblocks = 1024;
+    const float *yl = y_out, *tl = target;
+    float *gl = t.gy;
+    if (L != cs) {
+        hipLaunchKernelGGL(k_center_crop, dim3(1024), dim3(256), 0, s, (const float *)y_out, cs, L, nout, t.ycrop);
+        hipLaunchKernelGGL(k_center_crop, dim3(1024), dim3(256), 0, s, target, cs, L, nout, t.tcrop);
+        yl = t.ycrop;
+        tl = t.tcrop;
+        gl = t.gcrop;
+    }
+    hipLaunchKernelGGL(k_loss_grad, dim3(lblocks), dim3(256), 0, s, yl, tl, nout, w_l1, w_mse, gl, t.red);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, (const float *)t.red, lblocks, 1.f / (float)nout, loss_out);
+    ND_HIP(hipGetLastError());
+    if (w_ssim != 0.f || w_msssim != 0.f) {
+        hipLaunchKernelGGL(k_clip01, dim3(1024), dim3(256), 0, s, yl, nout, t.yclip);
+        int acc = 0;
+        if (w_ssim != 0.f) {
+            ND_TRY(nd_ssim_loss_grad(t.yclip, tl, B, 3, L, L, 0, w_ssim, loss_out, t.gssim, acc, t.ssim_ws, t.ssim_ws_bytes, s));
+            acc = 1;
+        }
+        if (w_msssim != 0.f)
+            ND_TRY(nd_ssim_loss_grad(t.yclip, tl, B, 3, L, L, 1, w_msssim, loss_out, t.gssim, acc, t.ssim_ws, t.ssim_ws_bytes, s));
+        hipLaunchKernelGGL(k_add_clip_grad, dim3(1024), dim3(256), 0, s, yl, (const float *)t.gssim, nout, gl);
+        ND_HIP(hipGetLastError());
+    }
+    if (L != cs) {
+        hipLaunchKernelGGL(k_center_uncrop, dim3(1024), dim3(256), 0, s, (const float *)t.gcrop, cs, L, nfull, t.gy);
+        ND_HIP(hipGetLastError());
+    }
+
+    return train_backward(c, grads, t.gy, bucket_ev);
+}
+extern "C" int nd_utnet_train_step(int funit, int flags, const float *params, float *grads, void *blobs, const float *x,
+                                   const float *target, float *y_out, float w_l1, float w_mse, float w_ssim, float w_msssim,
+                                   float *loss_out, int batch, int cs, int loss_cs, void *ws, size_t ws_bytes, void *stream) {
+    return train_step_impl(funit, flags, params, grads, blobs, x, target, y_out, w_l1, w_mse, w_ssim, w_msssim, loss_out, batch, cs,
+                           loss_cs, ws, ws_bytes, stream, nullptr);
+}
+// The same step for a data-parallel run that overlaps the gradient reduction with the backward pass: bucket_events[k]
+// (hipEvent_t, nd_utnet_grad_buckets of them) is recorded on `stream` as soon as every gradient of bucket k is final.
+extern "C" int nd_utnet_train_step_ev(int funit, int flags, const float *params, float *grads, void *blobs, const float *x,
+                                      const float *target, float *y_out, float w_l1, float w_mse, float w_ssim, float w_msssim,
+                                      float *loss_out, int batch, int cs, int loss_cs, void *ws, size_t ws_bytes, void *stream,
+                                      void *const *bucket_events, int n_events) {
+    if (!bucket_events || n_events != kNumBuckets) ND_FAIL(ND_EINVAL, "train step: %d bucket events expected", kNumBuckets);
+    return train_step_impl(funit, flags, params, grads, blobs, x, target, y_out, w_l1, w_mse, w_ssim, w_msssim, loss_out, batch, cs,
+                           loss_cs, ws, ws_bytes, stream, bucket_events);
+}
+// Buckets of the flat gradient buffer in the order the backward pass completes them (one per decoder / encoder level):
+// offsets / counts in floats.  Returns the number of buckets (9); fills at most `max` entries.
+extern "C" int nd_utnet_grad_buckets(int funit, size_t *offsets, size_t *counts, int max) {
+    if (funit < 8 || funit % 8) ND_FAIL(ND_EINVAL, "bad funit");
+    const ParamLayout pl = param_layout(funit);
+    const auto &names = tensor_names();
+    for (int k = 0; k < kNumBuckets && k < max; ++k) {
+        size_t lo = (size_t)-1, hi = 0;
+        for (size_t i = 0; i < names.size(); ++i) {
+            const std::string key = names[i].substr(0, names[i].find('.') == std::string::npos ? names[i].size() : names[i].find('.'));
+            if (bucket_of_key(key) != k) continue;
+            if (pl.off[i] < lo) lo = pl.off[i];
+            if (pl.off[i] + pl.cnt[i] > hi) hi = pl.off[i] + pl.cnt[i];
+        }
+        if (offsets) offsets[k] = lo;
+        if (counts) counts[k] = hi - lo;
+    }
+    return kNumBuckets;
+}
+
+// The two halves for torch.autograd (act: ND_ACT_PRELU | ND_ACT_ELU | ND_ACT_HARDSWISH, the reference constructor's choices,
+// networks/UtNet.py:17-26).  `ws` and `blobs` carry the forward's activations, pre-activations and packed weights to the
+// backward call: the caller keeps both untouched in between.  The input's own gradient is not produced (the first layer's data
+// gradient is skipped, as in the fused step): images are not trained.
+extern "C" int nd_utnet_train_forward(int funit, int act, int flags, const float *params, void *blobs, const float *x, float *y_out,
+                                      int batch, int cs, void *ws, size_t ws_bytes, void *stream) {
+    if (!x || !y_out) ND_FAIL(ND_EINVAL, "train forward: null pointer");
+    TrainCtx c;
+    ND_TRY(train_ctx(c, funit, flags, act, params, blobs, batch, cs, ws, ws_bytes, stream));
+    return train_forward(c, params, x, y_out);
+}
+extern "C" int nd_utnet_train_backward(int funit, int act, int flags, const float *params, float *grads, void *blobs, const float *gy,
+                                       int batch, int cs, void *ws, size_t ws_bytes, void *stream, void *const *bucket_events,
+                                       int n_events) {
+    if (!grads || !gy) ND_FAIL(ND_EINVAL, "train backward: null pointer");
+    if (bucket_events && n_events != kNumBuckets) ND_FAIL(ND_EINVAL, "train backward: %d bucket events expected", kNumBuckets);
+    TrainCtx c;
+    ND_TRY(train_ctx(c, funit, flags, act, params, blobs, batch, cs, ws, ws_bytes, stream));
+    return train_backward(c, grads, gy, bucket_events);
 }
 
 // torch.optim.Adam(params, lr, betas=(b1,b2), eps, amsgrad) on flat buffers; step = 1, 2, ...

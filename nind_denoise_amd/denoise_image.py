@@ -237,8 +237,12 @@ def denoise_file(model, inpath, outpath, cs, ucs, overlap, batch=32, whole_image
     device = torch.device(device) if device is not None else nn_common.default_device()
     if device is None or device.type != 'cuda':
         raise RuntimeError('denoise_file: no GPU; nind_denoise_amd has no CPU fallback')
-    frame = torch.from_numpy(np_imgops.img_path_to_np_flt(inpath)) if isinstance(inpath, (str, os.PathLike)) else inpath
+    raw_path = isinstance(inpath, (str, os.PathLike))
+    if raw_path and not os.path.isfile(inpath):
+        raise FileNotFoundError(inpath)
     with (gpu_lock if gpu_lock is not None else contextlib.nullcontext()):
+        # (decoded samples are uploaded as stored and converted to float32 on the GPU: np_imgops.img_path_to_device_flt)
+        frame = np_imgops.img_path_to_device_flt(inpath, device) if raw_path else inpath
         ds = OneImageDS(frame, cs, ucs, overlap, whole_image=whole_image, pad=pad, device=device)
         if whole_image:
             ybatch, usefuldims, _ = ds[0]
@@ -261,8 +265,8 @@ def denoise_file(model, inpath, outpath, cs, ucs, overlap, batch=32, whole_image
                 newimg = _denoise_frame_debug(model, ds, cs, ucs, overlap, batch, outpath, dbg_dir)
             else:
                 newimg = pipeline.denoise_frame(model, ds.inimg, cs, ucs, overlap, batch=batch, progress=progress)
-        host = newimg.cpu()       # (synchronises: the device section ends here)
-    pt_helpers.tensor_to_imgfile(host, outpath)
+        # (sample conversion / HWC transpose on the GPU, then the download: the device section ends inside this call)
+        pt_helpers.tensor_to_imgfile(newimg, outpath)
     return newimg
 
 

@@ -28,6 +28,87 @@ def nearest_valid_cs(cs):
     return max(104, 16 * k + 56)
 
 
+class _TrainState:
+    """Flat parameter / gradient buffers, packed-weight blobs and the training workspace of one module on one device
+    (nd_utnet_train_forward / nd_utnet_train_backward of include/nind_hip.h)."""
+
+    def __init__(self, model, device):
+        lib = _lib.load()
+        self.device = device
+        n = lib.nd_utnet_param_count(model.funit)
+        if n == 0:
+            raise ValueError(f"UtNet: funit={model.funit} is not supported by the HIP training path (multiple of 8)")
+        self.flat = torch.zeros(n, dtype=torch.float32, device=device)
+        self.grads = torch.zeros(n, dtype=torch.float32, device=device)
+        self.blobs = torch.empty(lib.nd_utnet_train_blob_bytes(model.funit), dtype=torch.uint8, device=device)
+        self.ranges = {}
+        for i, name in enumerate(_lib.utnet_tensor_names()):
+            off, cnt = ctypes.c_size_t(), ctypes.c_size_t()
+            _lib.check(lib.nd_utnet_param_range(model.funit, i, off, cnt))
+            self.ranges[name] = (off.value, cnt.value)
+        self.ws, self.ws_key = None, None
+        self.generation = 0          # bumped by every forward: a backward must follow ITS forward
+
+    def workspace(self, model, cs, batch):
+        if self.ws_key != (cs, batch):
+            lib = _lib.load()
+            nbytes = lib.nd_utnet_train_workspace_bytes(model.funit, cs, batch)
+            if nbytes == 0:
+                _lib.check(lib.nd_utnet_train_workspace_init(None, 0, model.funit, cs, batch, None), "UtNet training")
+            self.ws = None
+            self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            _lib.check(lib.nd_utnet_train_workspace_init(self.ws.data_ptr(), nbytes, model.funit, cs, batch, _lib.stream_ptr(self.device)),
+                       "nd_utnet_train_workspace_init")
+            self.ws_key = (cs, batch)
+        return self.ws
+
+
+class _UtNetFunction(torch.autograd.Function):
+    """UtNet.forward under autograd: forward = device-side weight packing + the conv stack with the pre-activations kept
+    (nd_utnet_train_forward), backward = activation / bias / weight / data gradients of every layer (nd_utnet_train_backward),
+    the kernels of the fused training step (csrc/utnet_train.hip).  Gradients are returned for the parameters; the input image
+    gets none (the reference never trains through it)."""
+
+    @staticmethod
+    def forward(ctx, model, names, x, *params):
+        st = model._train_state(x.device)
+        with torch.no_grad():
+            for n, p in zip(names, params):
+                off, cnt = st.ranges[n]
+                st.flat[off:off + cnt].copy_(p.detach().reshape(-1))
+        batch, cs = x.size(0), x.size(2)
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            ws = st.workspace(model, cs, batch)
+            _lib.check(_lib.load().nd_utnet_train_forward(model.funit, _lib.ACT[model.activation], model.flags, st.flat.data_ptr(),
+                                                          st.blobs.data_ptr(), x.data_ptr(), y.data_ptr(), batch, cs, ws.data_ptr(),
+                                                          ws.numel(), _lib.stream_ptr(x.device)), "nd_utnet_train_forward")
+        st.generation += 1
+        ctx.model, ctx.names, ctx.geom, ctx.generation = model, names, (batch, cs), st.generation
+        ctx.shapes = [p.shape for p in params]
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        model = ctx.model
+        st = model._train_state(gy.device)
+        if st.generation != ctx.generation:
+            raise RuntimeError("UtNet backward: another forward of this module ran under autograd since this graph was built; its "
+                               "activations are gone (one forward/backward in flight per module -- as the reference's training loop runs)")
+        batch, cs = ctx.geom
+        gy = gy.to(torch.float32).contiguous()
+        with torch.cuda.device(gy.device):
+            _lib.check(_lib.load().nd_utnet_train_backward(model.funit, _lib.ACT[model.activation], model.flags, st.flat.data_ptr(),
+                                                           st.grads.data_ptr(), st.blobs.data_ptr(), gy.data_ptr(), batch, cs,
+                                                           st.ws.data_ptr(), st.ws.numel(), _lib.stream_ptr(gy.device), None, 0),
+                       "nd_utnet_train_backward")
+        grads = []
+        for n, shape in zip(ctx.names, ctx.shapes):
+            off, cnt = st.ranges[n]
+            grads.append(st.grads[off:off + cnt].view(shape).clone())
+        return (None, None, None) + tuple(grads)
+
+
 class UtNet(nn.Module):
     # per-call arithmetic flags (nd_flags of include/nind_hip.h), overridable per instance:
     #   split_k = False  -> every output tile whole: a tile's bits do not depend on the batch grouping
@@ -165,6 +246,19 @@ class UtNet(nn.Module):
             if not valid_cs(cs):
                 raise ValueError(f"UtNet: tile size {cs} is not of the form 16k+56 (e.g. {nearest_valid_cs(cs)}); "
                                  "the reference network fails on it too")
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # the differentiable path: the reference trains through plain autograd (nn_common.py:146 `self.model.train()`,
+            # :198-218 forward / backward); an eval() module (nn_common.py:142, denoise_image.py:229) takes the inference path
+            # below, whose output carries no graph
+            if l.requires_grad:
+                raise NotImplementedError("UtNet: the gradient with respect to the input image is not produced by the HIP path")
+            if h != w:
+                raise ValueError(f"UtNet under autograd expects square crops, got {h}x{w}")
+            if self.compute_dtype != "f32":
+                raise NotImplementedError("UtNet under autograd runs in fp32 (the training step's arithmetic)")
+            named = [(n, p) for n, p in self.named_parameters()]
+            return _UtNetFunction.apply(self, tuple(n for n, _ in named), l.detach().to(torch.float32).contiguous(),
+                                        *[p for _, p in named])
         x = l.detach().to(torch.float32).contiguous()
         lib = _lib.load()
         with torch.cuda.device(x.device):
@@ -175,6 +269,12 @@ class UtNet(nn.Module):
                                                x.data_ptr(), y.data_ptr(), batch, h, w, ws.data_ptr(), ws.numel(),
                                                _lib.stream_ptr(x.device)), "nd_utnet_forward")
         return y
+
+    def _train_state(self, device):
+        st = getattr(self, "_tstate", None)
+        if st is None or st.device != device:
+            st = self._tstate = _TrainState(self, device)
+        return st
 
     def flops_per_tile(self, cs):
         return _lib.load().nd_utnet_flops(self.funit, cs)

@@ -377,7 +377,7 @@ def test_utnet_activation_variants_golden(dev, golden_dir):
     for act in ("ELU", "Hardswish"):
         net = UtNet(funit=8, activation=act)
         net.load_state_dict(synth.make_utnet_state_dict(funit=8, seed=11, activation=act))
-        y = net.to(dev)(torch.from_numpy(d["x"]).to(dev))
+        y = net.eval().to(dev)(torch.from_numpy(d["x"]).to(dev))
         assert_close(y, torch.from_numpy(d[f"y_{act}"]), act)
 
 
@@ -422,7 +422,7 @@ def test_utnet_vs_oracle_other_sizes(dev):
     sd = synth.make_utnet_state_dict(funit=16, seed=5)
     net = UtNet(funit=16)
     net.load_state_dict(sd)
-    net = net.to(dev)
+    net = net.eval().to(dev)
     for cs, B in ((104, 3), (136, 2), (184, 1)):
         x = torch.rand(B, 3, cs, cs, generator=torch.Generator().manual_seed(cs))
         with torch.no_grad():
@@ -511,7 +511,7 @@ def test_frame_end_to_end_vs_oracle(dev, whole_k):
     sd = synth.make_utnet_state_dict(funit=16, seed=9)
     net = UtNet(funit=16)
     net.load_state_dict(sd)
-    net = net.to(dev)
+    net = net.eval().to(dev)
     W, H, cs, ucs, ol = 333, 290, 120, 88, 16
     frame = synth.make_frame(W, H, seed=3)
 
@@ -571,6 +571,33 @@ def test_cli_end_to_end(dev, tmp_path):
     assert np.array_equal(t.cpu().numpy(), otiler.gather_tile(frame, grid, grid.size - 1))
     assert tuple(ud.tolist()) == grid.geom(grid.size - 1)[2] and tuple(us.tolist()) == grid.geom(grid.size - 1)[3]
     assert ud.dtype == torch.int32
+
+
+def test_device_side_sample_conversion_is_bit_identical(dev, tmp_path):
+    """CLI I/O with the sample conversions on the GPU (np_imgops.img_path_to_device_flt, pt_helpers.tensor_to_imgfile on a CUDA
+    tensor): the same IEEE float32 operations as the host path of np_imgops.py:12-29 / pt_helpers.py:22-34 -- frames and files
+    must be byte-identical."""
+    from nind_denoise_amd.common.libs import imgcodec, np_imgops, pt_helpers
+    rng = np.random.default_rng(5)
+    u16 = rng.integers(0, 65536, size=(37, 53, 3), dtype=np.uint16)
+    u16[0, :8, 0] = [0, 1, 32767, 32768, 65534, 65535, 255, 256]
+    imgcodec.write_tiff(str(tmp_path / "a.tif"), u16)
+    imgcodec.write_png(str(tmp_path / "a.png"), u16)
+    imgcodec.write_tiff(str(tmp_path / "b.tif"), (u16 >> 8).astype(np.uint8))
+    imgcodec.write_tiff(str(tmp_path / "c.tiff"), rng.standard_normal((37, 53, 3)).astype(np.float32))
+    for name in ("a.tif", "a.png", "b.tif", "c.tiff", "NIND_bananapi_ISO50_20_30_104.png"):
+        path = str(tmp_path / name) if not name.startswith("NIND") else os.path.join(os.path.dirname(__file__), "golden", name)
+        host = np_imgops.img_path_to_np_flt(path)
+        got = np_imgops.img_path_to_device_flt(path, dev)
+        assert got.dtype == torch.float32 and got.is_contiguous() and np.array_equal(got.cpu().numpy(), host), name
+    # writer: values below 0, above 1, exact .5 ties of x * 65535, denormals
+    t = torch.from_numpy(rng.uniform(-0.2, 1.2, size=(3, 41, 29)).astype(np.float32))
+    t[0, 0, :6] = torch.tensor([0.5 / 65535, 1.5 / 65535, 2.5 / 65535, 1.0, 0.0, 1e-40])
+    for ext in (".tif", ".png", ".tiff"):
+        pt_helpers.tensor_to_imgfile(t.clone(), str(tmp_path / ("h" + ext)))
+        pt_helpers.tensor_to_imgfile(t.to(dev), str(tmp_path / ("d" + ext)))
+        with open(tmp_path / ("h" + ext), "rb") as f1, open(tmp_path / ("d" + ext), "rb") as f2:
+            assert f1.read() == f2.read(), ext
 
 
 def test_resident_worker_serves_cli_clients(dev, tmp_path):
@@ -707,7 +734,7 @@ def test_utnet_non_square_and_whole_image(dev):
     sd = synth.make_utnet_state_dict(funit=16, seed=4)
     net = UtNet(funit=16)
     net.load_state_dict(sd)
-    net = net.to(dev)
+    net = net.eval().to(dev)
     x = torch.rand(2, 3, 104, 152, generator=torch.Generator().manual_seed(1))
     with torch.no_grad():
         ref = onet.utnet_forward(sd, x)
@@ -818,7 +845,7 @@ def test_frame_half_storage_fused_equals_unfused(dev, dtype, whole_k):
     from nind_denoise_amd.networks.UtNet import UtNet
     net = UtNet(funit=16)
     net.load_state_dict(synth.make_utnet_state_dict(funit=16, seed=9))
-    net = net.to(dev).set_compute_dtype(dtype)
+    net = net.eval().to(dev).set_compute_dtype(dtype)
     img = torch.from_numpy(synth.make_frame(333, 290, seed=3)).to(dev)
     a_roi = pipeline.denoise_frame(net, img, 120, 88, 16, batch=5)
     net.useful_only = False        # bit-for-bit equality holds between the two WHOLE-tile paths (fused / forward + stitch)
@@ -839,7 +866,7 @@ def test_frame_engine_streams_frames_in_order(dev):
     from nind_denoise_amd.serve import FrameEngine
     net = UtNet(funit=16)
     net.load_state_dict(synth.make_utnet_state_dict(funit=16, seed=2))
-    net = net.to(dev)
+    net = net.eval().to(dev)
     W, H, cs, ucs, ol = 300, 260, 120, 88, 16
     frames = [synth.make_frame(W, H, seed=s) for s in range(7)]
     eng = FrameEngine(net, W, H, cs, ucs, ol, batch=6, slots=3, device=dev)
@@ -1061,6 +1088,93 @@ def test_training_step_gradients_vs_autograd(dev, funit, cs, B, w_l1, w_mse):
         bar = 5e-3 if wide else 3e-4
         assert torch.isfinite(got).all() and err <= bar, (name, err, bar, scale)
     print(f"training step f{funit} cs{cs}: worst relative gradient error {worst:.2e}")
+
+
+def test_autograd_training_matches_fused_step(dev):
+    """Row f3 behind plain autograd: the reference's own statements (nn_common.py:198-218) -- model(x).clip(0, 1), a torch
+    criterion, loss.backward(), torch.optim.Adam(amsgrad) -- on the module, three updates, against UtNetTrainer (fused step +
+    nd_adam_step) from the same start: same outputs, same losses, same parameters."""
+    from nind_denoise_amd.networks.UtNet import UtNet
+    from nind_denoise_amd.train import UtNetTrainer
+    funit, cs, B, lr = 8, 104, 2, 3e-3
+    sd = synth.make_utnet_state_dict(funit=funit, seed=31, gain=1.8)
+    ref_net = UtNet(funit=funit)
+    ref_net.load_state_dict(sd)
+    tr = UtNetTrainer(ref_net, device=dev, lr=lr, beta1=0.75, weights={"L1": 0.0, "MSE": 1.0})
+    net = UtNet(funit=funit)
+    net.load_state_dict(sd)
+    net = net.to(dev).train()
+    opt = torch.optim.Adam(net.parameters(), lr=lr, betas=(0.75, 0.999), amsgrad=True)
+    g = torch.Generator().manual_seed(3)
+    for step in range(3):
+        x = torch.rand(B, 3, cs, cs, generator=g)
+        t = (x * 0.9 + 0.05 * torch.rand(B, 3, cs, cs, generator=g)).clip(0, 1)
+        y_ref, loss_ref = tr.forward_backward(x, t)
+        loss_ref = loss_ref.item()
+        tr.optimizer_step()
+        opt.zero_grad()
+        out = net(x.to(dev))
+        assert out.requires_grad
+        loss = F.mse_loss(out.clip(0, 1), t.to(dev))
+        loss.backward()
+        opt.step()
+        if step == 0:
+            assert torch.equal(out.detach(), y_ref)            # the same kernels on the same weights
+        else:                                                  # (torch's Adam and nd_adam_step round differently in the last bits)
+            assert (out.detach() - y_ref).abs().max().item() <= 1e-5, step
+        assert abs(loss.item() - loss_ref) <= 1e-6 * max(1.0, abs(loss_ref)), (step, loss.item(), loss_ref)
+    worst = 0.0
+    for (n1, p1), (n2, p2) in zip(net.named_parameters(), ref_net.named_parameters()):
+        assert n1 == n2
+        worst = max(worst, (p1.detach() - p2.detach()).abs().max().item())
+    assert worst <= 1e-6, worst
+    # the updated weights are what inference sees (torch bumped the parameters' versions: the packed blob is rebuilt)
+    net.eval()
+    with torch.no_grad():
+        xi = torch.rand(1, 3, cs, cs, generator=g).to(dev)
+        assert_close(net(xi), ref_net.eval()(xi), "inference after autograd training")
+    # one graph per forward: a second forward invalidates the first one's saved activations, loudly
+    net.train()
+    o1 = net(xi)
+    net(xi)
+    with pytest.raises(RuntimeError, match="another forward"):
+        o1.sum().backward()
+
+
+@pytest.mark.parametrize("activation", ["ELU", "Hardswish", "PReLU"])
+def test_autograd_gradients_all_activations(dev, activation):
+    """loss.backward() through the module for the three activations the reference constructor takes (networks/UtNet.py:17-26)
+    against torch autograd on the oracle (CPU)."""
+    from nind_denoise_amd.networks.UtNet import UtNet
+    from oracle import networks as onet
+    funit, cs, B = 8, 104, 2
+    # (seeds and the smooth MSE criterion of test_training_step_gradients_vs_autograd's first case: with an L1 term the sign of
+    #  g - t flips on pixels where the two forwards differ in the last bits, and the vanishing gradients of the deep layers of
+    #  these synthetic weights -- 1e-6 .. 1e-5 -- move by more than the bar)
+    sd = synth.make_utnet_state_dict(funit=funit, seed=31, activation=activation, gain=1.8)
+    net = UtNet(funit=funit, activation=activation)
+    net.load_state_dict(sd)
+    net = net.to(dev).train()
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(B, 3, cs, cs, generator=g)
+    t = (x * 0.9 + 0.05 * torch.rand(B, 3, cs, cs, generator=g)).clip(0, 1)
+    out = net(x.to(dev))
+    loss = F.mse_loss(out.clip(0, 1), t.to(dev))
+    loss.backward()
+    params = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    y = onet.utnet_forward(params, x, activation=activation)
+    lref = F.mse_loss(y.clip(0, 1), t)
+    lref.backward()
+    assert_close(out.detach(), y.detach(), f"autograd forward {activation}")
+    assert abs(loss.item() - lref.item()) <= 1e-5 * max(1.0, abs(lref.item()))
+    worst = 0.0
+    for name, p in net.named_parameters():
+        ref = params[name].grad
+        scale = max(ref.abs().max().item(), 1e-8)
+        err = (p.grad.cpu() - ref).abs().max().item() / scale
+        worst = max(worst, err)
+        assert torch.isfinite(p.grad).all() and err <= 1e-3, (activation, name, err, scale)   # (the fused step's own bar: 3e-4)
+    print(f"autograd {activation}: worst relative gradient error {worst:.2e}")
 
 
 def test_training_step_w2d_forward_with_preactivation_copy(dev):
