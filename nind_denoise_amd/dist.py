@@ -360,3 +360,61 @@ def average_gradients(flat, group=None):
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         flat.div_(world)
     return flat
+
+
+class BucketedGradientAverager:
+    """Data-parallel gradient mean that overlaps the backward pass (BASELINE configs[4]).
+
+    The flat state-dict-order gradient buffer is cut into the library's level buckets (nd_utnet_grad_buckets: up4 + tconvs4, ...,
+    convs1 -- the order in which the backward pass completes them).  The training step records one HIP event per bucket on the
+    compute stream as soon as the bucket is final (nd_utnet_train_step_ev / nd_utnet_train_backward); `reduce()` all-reduces
+    bucket k on a side stream behind event k, i.e. under the backward of the shallower levels, and the compute stream only waits
+    for the last (smallest) buckets.  On a gloo group (tests, the one-GPU rehearsal) the buckets are reduced one by one through
+    host memory after the step; with CPU tensors there are no events at all.  No-op without an initialised process group."""
+
+    def __init__(self, funit, flat, group=None):
+        import ctypes
+        lib = _lib.load()
+        n = lib.nd_utnet_grad_buckets(funit, None, None, 0)
+        if n <= 0:
+            _lib.check(n, "nd_utnet_grad_buckets")
+        off, cnt = (ctypes.c_size_t * n)(), (ctypes.c_size_t * n)()
+        _lib.check(min(0, lib.nd_utnet_grad_buckets(funit, off, cnt, n)), "nd_utnet_grad_buckets")
+        self.buckets = [(int(off[k]), int(cnt[k])) for k in range(n)]
+        assert sum(c for _, c in self.buckets) == flat.numel(), "gradient buckets do not tile the flat buffer"
+        self.flat, self.group = flat, group
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.events, self.event_ptrs, self.stream = None, None, None
+        if flat.is_cuda:
+            with torch.cuda.device(flat.device):
+                self.stream = torch.cuda.Stream()
+                self.events = [torch.cuda.Event() for _ in range(n)]
+                for e in self.events:
+                    e.record()                    # (a torch event owns its hipEvent_t from the first record on)
+                self.event_ptrs = (ctypes.c_void_p * n)(*[e.cuda_event for e in self.events])
+
+    def reduce(self):
+        """Call right after the step was enqueued: averages self.flat over the group, bucket by bucket."""
+        if not self.active:
+            return self.flat
+        world = dist.get_world_size(self.group)
+        if self.flat.is_cuda and not _host_staged(self.group):
+            cur = torch.cuda.current_stream(self.flat.device)
+            with torch.cuda.stream(self.stream):
+                for k, (off, cnt) in enumerate(self.buckets):
+                    self.stream.wait_event(self.events[k])
+                    part = self.flat[off:off + cnt]
+                    dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
+                    part.div_(world)
+            cur.wait_stream(self.stream)
+        else:
+            for off, cnt in self.buckets:
+                part = self.flat[off:off + cnt]
+                if part.is_cuda:
+                    h = part.cpu()
+                    dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                    part.copy_(h)
+                else:
+                    dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
+                part.div_(world)
+        return self.flat

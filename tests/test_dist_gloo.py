@@ -255,3 +255,44 @@ def test_parameter_broadcast_world_2():
     assert n0 == n1 == 4 * sum(v.numel() for v in ref.values())
     for k, v in ref.items():
         assert np.array_equal(sd0[k], v.numpy()) and np.array_equal(sd1[k], v.numpy())
+
+
+def _bucket_worker(rank, world, port, outq):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nind_denoise_amd import _lib
+        from nind_denoise_amd import dist as ndist
+        n = _lib.load().nd_utnet_param_count(8)
+        flat = torch.arange(n, dtype=torch.float32) % 1000 * (rank + 1)
+        av = ndist.BucketedGradientAverager(8, flat)
+        av.reduce()
+        outq.put((rank, flat.numpy(), av.buckets))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_gradient_average_world_2():
+    """The level buckets of the flat gradient buffer (nd_utnet_grad_buckets) tile it in the backward pass's completion order, and
+    reducing them one by one gives the plain mean."""
+    from nind_denoise_amd import _lib
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n = _lib.load().nd_utnet_param_count(8)
+    want = (np.arange(n, dtype=np.float32) % 1000) * 1.5
+    for _, flat, buckets in got:
+        assert np.array_equal(flat, want)
+        assert len(buckets) == 9 and sum(c for _, c in buckets) == n
+        ends = sorted((o, o + c) for o, c in buckets)
+        assert ends[0][0] == 0 and all(ends[i][1] == ends[i + 1][0] for i in range(8)) and ends[-1][1] == n
+        # completion order of the backward pass: decoder level 4 first (the end of the state dict), convs1 (offset 0) last
+        assert buckets[-1][0] == 0 and buckets[0][0] == max(o for o, _ in buckets)

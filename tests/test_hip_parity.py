@@ -1177,6 +1177,56 @@ def test_autograd_gradients_all_activations(dev, activation):
     print(f"autograd {activation}: worst relative gradient error {worst:.2e}")
 
 
+def _ddp_worker(port, outq):
+    import torch.distributed as tdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from nind_denoise_amd.networks.UtNet import UtNet
+    from nind_denoise_amd.train import UtNetTrainer
+    d = torch.device("cuda", 0)
+    torch.cuda.set_device(d)
+    tdist.init_process_group("nccl", rank=0, world_size=1, device_id=d)
+    try:
+        res = {}
+        for overlapped in (False, True):
+            net = UtNet(funit=8)
+            net.load_state_dict(synth.make_utnet_state_dict(funit=8, seed=31, gain=1.8))
+            tr = UtNetTrainer(net, device=d, weights={"L1": 0.2, "MSE": 0.8})
+            tr.averager.active = overlapped      # world size 1: force the bucket-by-bucket RCCL path (sum over one rank, / 1)
+            g = torch.Generator().manual_seed(3)
+            x = torch.rand(2, 3, 104, 104, generator=g)
+            t = (x * 0.9 + 0.05 * torch.rand(2, 3, 104, 104, generator=g)).clip(0, 1)
+            for _ in range(2):
+                tr.learn(x, t)
+            torch.cuda.synchronize()
+            res[overlapped] = (tr.flat.cpu().numpy(), tr.grads.cpu().numpy())
+        outq.put(res)
+    finally:
+        tdist.destroy_process_group()
+
+
+def test_bucketed_gradient_reduce_over_rccl(dev):
+    """BASELINE configs[4] building block: the training step records one event per level bucket while the backward pass runs
+    (nd_utnet_train_step_ev) and the reducer all-reduces each bucket behind its event on a side stream (RCCL, world size 1 here:
+    the transport and the event / stream ordering run, the sum is over one rank): two updates give the same parameters and
+    gradients as without the reducer, bit for bit."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_ddp_worker, args=(port, q))
+    p.start()
+    res = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert np.array_equal(res[False][0], res[True][0]) and np.array_equal(res[False][1], res[True][1])
+    assert np.isfinite(res[True][1]).all() and np.abs(res[True][1]).max() > 0
+
+
 def test_training_step_w2d_forward_with_preactivation_copy(dev):
     # From 512 workgroup tiles up the training forward runs a 3x3 layer through conv_w2d, which then writes the pre-activation copy
     # itself (9 crops of 184 pixels: 595 tiles on the first level), and every data gradient may take that kernel: the whole step
