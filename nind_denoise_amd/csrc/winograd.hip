@@ -292,13 +292,13 @@ __global__ __launch_bounds__(NTL * (T + 2)) void k_wino_in2(const f32x4 *__restr
 //   output: pass 1 thread (column j, tile)  loads m[0..A)[j] (tile-contiguous), column transform (A -> T) -> LDS
 //           pass 2 thread (row i < T, tile) row transform, bias, activation -> LDS row image [T][32 tiles x T pixels]
 //           pass 3 all threads              pixel-contiguous stores of the T rows (+ the 2x2 max pool of the tile rows, T even)
-template <int T>
-__global__ __launch_bounds__(32 * (T + 2)) void k_wino_out2(const f32x4 *__restrict__ m, long mnp, long mbs, int B, int TY, int TX, int Hv,
+template <int T, int NTL>
+__global__ __launch_bounds__(NTL * (T + 2)) void k_wino_out2(const f32x4 *__restrict__ m, long mnp, long mbs, int B, int TY, int TX, int Hv,
                                                              int Wv, const float *__restrict__ bias, int act, float slope_imm,
                                                              const float *__restrict__ slope_dev, f32x4 *__restrict__ out, long onp,
                                                              int out_plane0, long out_img_stride, int Wo, int opad, f32x4 *__restrict__ pool, long pnp,
                                                              int Hp, int Wp, int ppad) {
-    constexpr int A = Wino<T>::A, NTL = 32, RS = T * A + 1, NTH = 32 * A;
+    constexpr int A = Wino<T>::A, RS = T * A + 1, NTH = NTL * A;
     __shared__ f32x4 sr[NTL * RS];
     __shared__ f32x4 so[T][NTL * T];
     const long tiles = (long)B * TY * TX;
@@ -376,6 +376,7 @@ __global__ __launch_bounds__(32 * (T + 2)) void k_wino_out2(const f32x4 *__restr
     }
 }
 
+constexpr int kOutNtl = 32;   // tiles per workgroup of the F(6x6) output transform (16: 21.8 KB of LDS, 32: 43.5 KB; measured equal within 1 %)
 int positions(int T) { return (T + 2) * (T + 2); }
 size_t gemm_floats(int cin, int cout) { return nd_packed_floats(ND_CONV1, cin, cout, ND_F32); }
 
@@ -554,10 +555,15 @@ int nd_launch_conv_wino(int T, const ConvDesc &d, void *scratch, size_t scratch_
         Wp = q.Wb;
         ppad = q.pad;
     }
-    dim3 go2((unsigned)((g.tiles + 31) / 32), out_planes);
-    if (T == 6)
-        hipLaunchKernelGGL(k_wino_out2<6>, go2, dim3(256), 0, s, (const f32x4 *)m, g.mnp, g.mbs, d.in.B, g.TY, g.TX, g.Hv, g.Wv, bias,
+    if (T == 6 && kOutNtl == 16) {
+        dim3 go2((unsigned)((g.tiles + 15) / 16), out_planes);
+        hipLaunchKernelGGL((k_wino_out2<6, 16>), go2, dim3(128), 0, s, (const f32x4 *)m, g.mnp, g.mbs, d.in.B, g.TY, g.TX, g.Hv, g.Wv, bias,
                            d.act, d.slope, d.slope_dev, out, d.out.np(), d.out_plane0, (long)d.out.Hb * d.out.Wb, d.out.Wb, d.out.pad, pool, pnp, Hp, Wp, ppad);
+    } else if (T == 6) {
+        dim3 go2((unsigned)((g.tiles + 31) / 32), out_planes);
+        hipLaunchKernelGGL((k_wino_out2<6, 32>), go2, dim3(256), 0, s, (const f32x4 *)m, g.mnp, g.mbs, d.in.B, g.TY, g.TX, g.Hv, g.Wv, bias,
+                           d.act, d.slope, d.slope_dev, out, d.out.np(), d.out_plane0, (long)d.out.Hb * d.out.Wb, d.out.Wb, d.out.pad, pool, pnp, Hp, Wp, ppad);
+    }
     else if (T == 2)
         hipLaunchKernelGGL(k_wino_output<2>, go, dim3(128), 0, s, (const f32x4 *)m, g.mnp, g.mbs, d.in.B, g.TY, g.TX, g.Hv, g.Wv, bias,
                            d.act, d.slope, d.slope_dev, out, d.out.np(), d.out_plane0, d.out.Hb, d.out.Wb, d.out.pad, pool, pnp, Hp, Wp, ppad);
