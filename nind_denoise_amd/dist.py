@@ -234,8 +234,9 @@ class ShardedFrameStream:
 
     def run(self, frames, n_frames):
         """Generator.  `frames`: iterable of [3,H,W] tensors on `root` (ignored elsewhere); every rank passes the same `n_frames`.
-        Yields (index, canvas) on root as frames complete, in order -- the canvas is a ring slot, valid until two more frames
-        have been taken from the generator; yields (index, None) on the other ranks."""
+        Yields (index, canvas) on root as frames complete, in order -- the canvas is a ring slot: use it (stream-ordered work on
+        the current stream is enough, e.g. a copy) BEFORE advancing the generator again, which enqueues the compute that reuses
+        the slot; yields (index, None) on the other ranks."""
         geo = self.geo
         it = iter(frames) if self.is_root else None
 
