@@ -62,6 +62,14 @@ def test_tile_geometry_errors():
         _lib.tile_geom(99, 500, 700, 264, 200, 64)
 
 
+def _up_row(m, cout, cpp=4):
+    """GEMM row m of a 2x2 stride-2 transpose -> (a, b, co) (nd_up_row of csrc/nd_common.h: the two lane halves of an MFMA
+    accumulator group are the output columns 2x, 2x + 1 of one channel group, so that a wave stores contiguous runs):
+    m = 2 cpp (a * cout / cpp + group) + cpp * b + e, co = cpp * group + e; cpp = 4 channels per plane element in fp32."""
+    e, b, g = m % cpp, (m // cpp) & 1, m // (2 * cpp)
+    return g // (cout // cpp), b, cpp * (g % (cout // cpp)) + e
+
+
 def _ref_pack(kind, cin, cout, w):
     taps = 9 if kind in ("conv3", "convT3") else 1
     M = 4 * cout if kind == "convT2s2" else cout
@@ -84,8 +92,8 @@ def _ref_pack(kind, cin, cout, w):
                         elif kind == "convT3":
                             v = w[ci, m, 2 - t // 3, 2 - t % 3]
                         elif kind == "convT2s2":
-                            ab, co = divmod(m, cout)
-                            v = w[ci, co, ab >> 1, ab & 1]
+                            a, b, co = _up_row(m, cout)
+                            v = w[ci, co, a, b]
                         else:
                             v = w[m, ci, 0, 0]
                         out[mt, kb, t, lane, s] = v
@@ -107,7 +115,10 @@ def test_weight_packing(kind, cin, cout):
     assert np.array_equal(packed.numpy()[:ref.size], ref)
     bias = packed.numpy()[ref.size:]
     M = 4 * cout if kind == "convT2s2" else cout
-    assert np.array_equal(bias[:M], np.tile(b.numpy(), 4 if kind == "convT2s2" else 1))
+    want = b.numpy()[[_up_row(m, cout)[2] for m in range(M)]] if kind == "convT2s2" else b.numpy()
+    assert np.array_equal(bias[:M], want)
+    if kind == "convT2s2":   # every (a, b, co) appears exactly once
+        assert sorted(_up_row(m, cout) for m in range(M)) == [(a, b_, c) for a in range(2) for b_ in range(2) for c in range(cout)]
     assert not bias[M:].any()
     with pytest.raises(MemoryError):
         _lib.check(lib.nd_layer_pack(_lib.KIND[kind], cin, cout, _lib.ND_F32, w.data_ptr(), b.data_ptr(), packed.data_ptr(), 16))

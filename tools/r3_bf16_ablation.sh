@@ -1,3 +1,7 @@
+# Round-3 timing experiments on the 16-bit conv_qp kernel (GPU box, via gpurun).  Needs three extra builds next to the product library:
+#   make -C nind_denoise_amd/csrc ABLATE=1 BUILD=$PWD/nind_denoise_amd/csrc/build_abl OUT=$PWD/nind_denoise_amd/libnind_hip_abl.so
+#   make -C nind_denoise_amd/csrc NUSE=2   BUILD=.../build_n2 OUT=.../libnind_hip_n2.so      (and NUSE=3 -> libnind_hip_n3.so)
+# Output: gpurun_out/r3_abl.log (kept as profiles/r03_bf16_conv_qp_ablation.log), gpurun_out/r3_cli_stages.log
 set -e
 cd $GRAFT_REPO_ROOT
 timeout -k 10 300 python tools/prof_cli_stages.py > gpurun_out/r3_cli_stages.log 2>&1 || { tail -20 gpurun_out/r3_cli_stages.log; exit 1; }

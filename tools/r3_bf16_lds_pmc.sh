@@ -1,3 +1,5 @@
+# Round-3 diagnostics (GPU box, via gpurun): the bf16 MFMA shape micro-benchmark and two LDS / wait counter passes over the bf16 bench.
+# Output: gpurun_out/r3_ubench_bf16_shape.log, gpurun_out/r3_bf16_lds_pmc.json (kept under profiles/r03_*)
 set -e
 R=$GRAFT_REPO_ROOT
 cd $R/tools/ubench && timeout -k 10 300 ./mfma_bf16_shape > $R/gpurun_out/r3_ubench_bf16_shape.log 2>&1

@@ -1,3 +1,4 @@
+# The whole -m gpu suite, the two stack tables and the CLI wall-time record in one gpurun call.
 set -e
 cd $GRAFT_REPO_ROOT
 timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/r3_pytest_all.log 2>&1 || { tail -40 gpurun_out/r3_pytest_all.log; exit 1; }
