@@ -316,9 +316,11 @@ def main(argv=None, cwd=None, model_cache=None, gpu_lock=None):
         path = nn_common.Model.complete_path(path=args.model_path, keyword='generator', models_dpath=args.models_dpath)
         st = os.stat(path)
         key = (args.g_network, os.path.realpath(path), st.st_mtime_ns, st.st_size, args.model_parameters or '', str(device))
-        model = model_cache.get(key)
-        if model is None:
-            model = model_cache[key] = load()
+        import contextlib
+        with (gpu_lock if gpu_lock is not None else contextlib.nullcontext()):   # (two first requests must not both load the model)
+            model = model_cache.get(key)
+            if model is None:
+                model = model_cache[key] = load()
     start_time = time.time()
     denoise_file(model, args.input, args.output, args.cs, args.ucs, args.overlap, batch=args.batch_size or 64,
                  whole_image=args.whole_image, pad=args.pad, max_subpixels=args.max_subpixels, device=device, debug=args.debug,

@@ -142,6 +142,7 @@ class Worker:
         self.path = path
         self.models = {}                    # denoise_image.main's model cache: (network, file, mtime, size, parameters, device) -> module
         self.gpu_lock = threading.Lock()
+        self.count_lock = threading.Lock()
         self.stop = threading.Event()
         self.served = 0
         self.log = log or (lambda m: None)
@@ -186,7 +187,8 @@ class Worker:
                 finally:
                     out_router.local.sink = None
                     err_router.local.sink = None
-                self.served += 1
+                with self.count_lock:
+                    self.served += 1
                 send({"exit": int(status)})
             except (OSError, ValueError) as e:      # client went away / malformed request
                 self.log(f"request dropped: {e}")
