@@ -1646,6 +1646,28 @@ def test_pipelined_frame_stream_with_hip_compute(dev, world):
             assert np.abs(got[k] - ref).max() <= 1e-6 and (got[k] == ref).mean() > 0.7
 
 
+def test_bench_n2_rehearsal_line(dev):
+    """`bench.py --gpus 2` end to end on the one-GPU box (ND_BENCH_REHEARSAL=1: both ranks on GPU 0, messages over gloo): the launcher
+    spawns the ranks, the default N > 1 mode is the pipelined tile-shard stream, the parameters are broadcast from rank 0, rank 0
+    prints ONE JSON line that names the partition and carries the pipeline / replicas keys."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ND_BENCH_REHEARSAL="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--width", "1500",
+                        "--height", "1100", "--funit", "16", "--batch", "32", "--no-roofline"], env=env, cwd=root, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 3 and d["value"] > 0
+    assert "tile-shard x2" in d["config"]["parallelism"] and "pipelined" in d["config"]["parallelism"]
+    assert d["pipeline"]["compute_only_ms_largest_shard"] > 0 and 0 < d["pipeline"]["exchange_hidden_frac"] <= 1
+    assert d["frame_shard"]["frames_per_step"] == 2 and "REPLICAS" in d["frame_shard"]["note"]
+    assert d["weight_broadcast"]["bytes"] > 0 and "REHEARSAL" in d["data"]
+
+
 # ---------------------------------------------------------------------------- fixtures executed by the reference itself
 
 def test_whole_image_item_vs_reference_fixture(dev, golden_dir):
