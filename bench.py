@@ -231,6 +231,9 @@ def roofline_report(steps, dtype, cs, batch, funit):
         f["bytes"] += byts
         f["launches"] += launches
 
+    for i, s in enumerate(steps):
+        # a direct 3x3 layer whose pool step took no time of its own wrote the pooled tensor from its epilogue (16-bit storage)
+        s["pools"] = s["form"] == "direct" and i + 1 < len(steps) and steps[i + 1]["form"] == "pool" and steps[i + 1]["ms"] <= 0.02
     for s in steps:
         if s["form"] == "pool":
             # (fp32 default path: MaxPool2d(2) is fused into the producing layer's epilogue -- no launch, no time of its own)
@@ -248,6 +251,8 @@ def roofline_report(steps, dtype, cs, batch, funit):
                 add("three-pass Winograd layers (transforms + GEMMs)", "mfma", s["ms"], s["flop"], s["mfma_flop"], s["bytes"], launches=3)
         elif s["kind"] == 2:
             add("conv_qp up (ConvTranspose2d 2x2 s2)", "mfma", s["ms"], s["flop"], s["mfma_flop"], s["bytes"])
+        elif s["pools"]:
+            add("conv_qp direct 3x3 + fused 2x2 max pool (2-row band pixel order, quad maxima in the epilogue)", "mfma", s["ms"], s["flop"], s["mfma_flop"], s["bytes"])
         else:
             add("conv_qp direct 3x3", "mfma", s["ms"], s["flop"], s["mfma_flop"], s["bytes"])
     total_ms = sum(s["ms"] for s in steps)

@@ -62,6 +62,8 @@ typedef enum nd_flags {
                                  128 channels up, 1-D F(4,3) inside the implicit-GEMM kernel below; ~1e-5 re-association)   */
     ND_FLAG_W1D_REGS = 4,     /* A/B switch: the 1-D F(4,3) layers through the kernel that transforms in registers (conv_w1d)
                                  instead of the one that shares the transform through LDS (conv_w2d, the default)            */
+    ND_FLAG_UNFUSED_POOL = 16, /* A/B switch: every MaxPool2d(2) as its own kernel (default: written from the producing layer's
+                                 epilogue wherever its kernel can -- identical values)                                        */
     ND_FLAG_FULL_TILES = 8    /* nd_utnet_denoise_tiles / nd_utnet_profile_stack: compute every layer on the whole tile, as
                                  UtNet.forward does.  Default there: the last decoder levels compute only the pixels that the
                                  useful crop [pad, cs - pad) of a tile can reach (denoise_image.py:249-258 discards the rest of

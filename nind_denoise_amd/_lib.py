@@ -14,7 +14,7 @@ DTYPE = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "f16": 2, 
 ACT = {"none": 0, "PReLU": 1, "ELU": 2, "Hardswish": 3}
 KIND = {"conv3": 0, "convT3": 1, "convT2s2": 2, "conv1": 3, "conv2s2": 4}
 # nd_flags (include/nind_hip.h): per-call arithmetic switches
-FLAG_NO_SPLITK, FLAG_DIRECT_CONV, FLAG_W1D_REGS, FLAG_FULL_TILES = 1, 2, 4, 8
+FLAG_NO_SPLITK, FLAG_DIRECT_CONV, FLAG_W1D_REGS, FLAG_FULL_TILES, FLAG_UNFUSED_POOL = 1, 2, 4, 8, 16
 
 
 class StepProfile(ctypes.Structure):

@@ -49,7 +49,9 @@ static void valid_grid(int taps, const QpBuf &in, int *Hv, int *Wv, int *stride)
     *Wv = taps == 9 ? in.Wb - 2 : (in.Wb - 2 * in.pad) / *stride;
 }
 // (Hv_o x Wv_o > 0: the valid grid is a region of the buffer's -- same strides, more row / image gaps per tile)
-static int tile_span(const Variant &V, const QpBuf &in, bool cross, int Hv_o = 0, int Wv_o = 0) {
+// band2: the pixels of an image are enumerated over 2-row bands (ConvParams::band2) -- a tile of n pixels starting at column x0 of a
+// band ends on the lower row of a later band; the stage image is the linear range between its first and last input pixel
+static int tile_span(const Variant &V, const QpBuf &in, bool cross, int Hv_o = 0, int Wv_o = 0, bool band2 = false) {
     const int taps = V.taps;
     int Hv, Wv, s;
     valid_grid(taps, in, &Hv, &Wv, &s);
@@ -60,6 +62,14 @@ static int tile_span(const Variant &V, const QpBuf &in, bool cross, int Hv_o = 0
     const int n = V.nblk;
     // consecutive valid pixels are s input pixels apart; every row end adds s*(Wb - Wv), every image end the rest of the image
     int span = s * n + s * (in.Wb - Wv) * ((n - 1) / Wv + 1);
+    if (band2) {
+        span = 0;
+        for (int x0 = 0; x0 < Wv; ++x0) {
+            const int last = 2 * x0 + n - 1, row1 = 2 * (last / (2 * Wv)) + 1, x1 = (last % (2 * Wv)) >> 1;
+            const int sp = row1 * in.Wb + x1 - x0 + 1;
+            if (sp > span) span = sp;
+        }
+    }
     if (cross) span += (in.Hb * in.Wb - Hv * s * in.Wb) * ((n - 1) / (Hv * Wv) + 1);
     const long whole = (long)in.B * in.Hb * in.Wb;   // a tile never reads past the pixels in use (tiny images: 3x3 at the bottom)
     if (cross && span > whole) span = (int)whole;
@@ -70,13 +80,14 @@ static size_t lds_for(const Variant &V, int G) {
     return (size_t)V.nstage * ((size_t)(V.mblk / 32) * V.kbc * V.taps * 1024 + (size_t)2 * V.kbc * G * 1024);
 }
 // tiles may cross images when that still fits the LDS (small images: no padding of every image to a tile multiple)
-static size_t variant_lds(const Variant &V, const QpBuf &in, bool *cross_out = nullptr, int *G_out = nullptr, int Hv_o = 0, int Wv_o = 0) {
+static size_t variant_lds(const Variant &V, const QpBuf &in, bool *cross_out = nullptr, int *G_out = nullptr, int Hv_o = 0, int Wv_o = 0,
+                          bool band2 = false) {
     const size_t kMax = 160 * 1024;
-    int G = (tile_span(V, in, true, Hv_o, Wv_o) + 63) / 64;
+    int G = (tile_span(V, in, true, Hv_o, Wv_o, band2) + 63) / 64;
     bool cross = true;
     if (lds_for(V, G) > kMax) {
         cross = false;
-        G = (tile_span(V, in, false, Hv_o, Wv_o) + 63) / 64;
+        G = (tile_span(V, in, false, Hv_o, Wv_o, band2) + 63) / 64;
     }
     if (cross_out) *cross_out = cross;
     if (G_out) *G_out = G;
@@ -200,6 +211,7 @@ int nd_launch_split_finish(const ConvParams &p, int n_split_tiles, int mblk, int
 static int pick_variant(const ConvDesc &d, int M) {
     // (a region of interest shortens the rows of valid pixels: more row gaps per tile, a longer LDS halo image)
     const int Hr = d.roi_rows > 0 ? d.roi_rows : 0, Wr = d.roi_rows > 0 ? d.roi_cols : 0;
+    const bool band2 = d.pool != nullptr;   // fused pool: 2-row band enumeration, a longer stage image
     const int taps = nd_taps(d.kind);
     const bool up = d.kind == ND_CONVT2S2;
     const int dt = d.in.dt;
@@ -222,11 +234,11 @@ static int pick_variant(const ConvDesc &d, int M) {
                 const Variant &V = variant_at(g0 + c.v);
                 if (c.v == 14 && (M < 128 || dt == ND_F32)) continue;
                 bool cross = true;
-                if (variant_lds(V, d.in, &cross, nullptr, Hr, Wr) > kMaxLds) continue;
+                if (variant_lds(V, d.in, &cross, nullptr, Hr, Wr, band2) > kMaxLds) continue;
                 const long pv = (long)Hv * Wv;
                 const long tn = cross ? ((long)d.in.B * pv + V.nblk - 1) / V.nblk : ((pv + V.nblk - 1) / V.nblk) * d.in.B;
                 const long tiles = tn * ((M + V.mblk - 1) / V.mblk);
-                const long cap = d.part && !d.nosplit ? (long)(d.part_bytes / ((size_t)V.mblk * V.nblk * 4)) : 0;
+                const long cap = d.part && !d.nosplit && !band2 ? (long)(d.part_bytes / ((size_t)V.mblk * V.nblk * 4)) : 0;
                 const double cost = plan_split(tiles, KB / V.kbc, cus, cap, kSplitOver).time * V.nblk * c.unit;
                 if (best_v < 0 || cost < best) {
                     best = cost;
@@ -237,7 +249,7 @@ static int pick_variant(const ConvDesc &d, int M) {
         }
         const int order[] = {M <= 32 ? 3 : 0, 0, 1, 2};
         for (int v : order)
-            if (variant_lds(variant_at(g0 + v), d.in, nullptr, nullptr, Hr, Wr) <= kMaxLds) return g0 + v;
+            if (variant_lds(variant_at(g0 + v), d.in, nullptr, nullptr, Hr, Wr, band2) <= kMaxLds) return g0 + v;
         return g0 + 2;
     }
     if (taps == 4) return g0 + (variant_lds(variant_at(g0 + 12), d.in, nullptr, nullptr, Hr, Wr) <= kMaxLds ? 12 : 13);
@@ -258,6 +270,20 @@ static int pick_variant(const ConvDesc &d, int M) {
         return cand[n - 1];
     }
     return g0 + 4;
+}
+
+// can this layer write its 2x2-pooled tensor itself (conv_qp, 16-bit storage)?  Needs even output sizes and a workgroup shape whose
+// stage images hold the longer pixel range of the 2-row band enumeration
+bool nd_conv_pool_fits(const ConvDesc &d) {
+    if (!d.pool || d.in.dt == ND_F32 || nd_taps(d.kind) != 9 || d.roi_rows > 0 || d.pre || d.nbatch > 1) return false;
+    if (((d.in.Hb - 2) | (d.in.Wb - 2)) & 1) return false;
+    // measured at 160 tiles of 264 (bf16; same box, flags 16 against 0): conv + pool kernel 1.240 -> 1.05 ms on the 264-pixel level,
+    // 0.842 -> 0.78 on the 128-pixel level, 0.621 -> 0.609 and 0.479 -> 0.480 below: the quad maxima, second rounding and pooled
+    // stores cost the epilogue about what the separate kernel costs once the tensor is small -- fuse the large levels only
+    if ((long)(d.in.Hb - 2) * (d.in.Wb - 2) < 100L * 100) return false;
+    const int v = pick_variant(d, d.cout);
+    if (v < 0 || v >= g_nvariants) return false;
+    return variant_lds(variant_at(v), d.in, nullptr, nullptr, 0, 0, true) <= kMaxLds;
 }
 
 // does a layer restricted to the region d.roi_* have a workgroup shape whose LDS stage images fit?  (a region much narrower than the
@@ -341,8 +367,22 @@ int nd_launch_conv(const ConvDesc &d, hipStream_t stream) {
                 d.out.pad, d.in.B, oh, ow);
     if (d.out_plane0 + d.cout / nd_cpp(dt) > d.out.planes) ND_FAIL(ND_EINVAL, "conv: destination planes overflow");
 
+    // fused MaxPool2d(2) (16-bit storage): 2-row band enumeration of the pixels, pooled tensor written from the epilogue
+    if (d.pool) {
+        const QpBuf &q = *d.pool;
+        if (dt == ND_F32 || taps != 9 || up || roi || d.pre || d.nbatch > 1 || (p.Hv & 1) || (p.Wv & 1))
+            ND_FAIL(ND_EINVAL, "conv: a fused pool needs a whole 16-bit 3x3 layer with even output sizes (got %d x %d, dtype %d)", p.Hv, p.Wv, dt);
+        if (q.dt != dt || q.B != d.in.B || q.Hb - 2 * q.pad != p.Hv / 2 || q.Wb - 2 * q.pad != p.Wv / 2 || q.planes < d.cout / nd_cpp(dt))
+            ND_FAIL(ND_EINVAL, "conv: pooled destination does not fit %d x %d x %d", d.cout, p.Hv / 2, p.Wv / 2);
+        p.pool = (f32x4 *)q.base;
+        p.pool_plane = q.np();
+        p.pool_P = q.Hb * q.Wb;
+        p.pool_W = q.Wb;
+        p.pool_pad = q.pad;
+        p.band2 = 1;
+    }
     bool cross = true;
-    const size_t lds = variant_lds(V, d.in, &cross, &p.G, roi ? p.Hv : 0, roi ? p.Wv : 0);
+    const size_t lds = variant_lds(V, d.in, &cross, &p.G, roi ? p.Hv : 0, roi ? p.Wv : 0, p.band2 != 0);
     if (lds > kMaxLds) ND_FAIL(ND_EINVAL, "conv: %zu B of LDS needed (row width %d too large for variant %s)", lds, p.Wb, V.name);
     if ((int)lds > g_lds_set[dev][v].load(std::memory_order_relaxed)) {
         ND_HIP(hipFuncSetAttribute((const void *)V.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -371,7 +411,8 @@ int nd_launch_conv(const ConvDesc &d, hipStream_t stream) {
     const long ntiles = (long)p.tiles_per_problem * (d.nbatch > 1 ? d.nbatch : 1);
     const int per_cu = lds * 2 <= kMaxLds && V.threads <= 256 ? 2 : 1;
     const long slots = (long)ncus * per_cu;
-    const long cap = d.part && !d.nosplit ? (long)(d.part_bytes / ((size_t)V.mblk * V.nblk * 4)) : 0;
+    // (a layer that pools keeps its tiles whole: the split-K finish kernel sees no neighbours)
+    const long cap = d.part && !d.nosplit && !p.band2 ? (long)(d.part_bytes / ((size_t)V.mblk * V.nblk * 4)) : 0;
     const SplitPlan sp = plan_split(ntiles, KB / V.kbc, slots, cap, kSplitOver);
     p.split_first = sp.first;
     p.S = sp.S;

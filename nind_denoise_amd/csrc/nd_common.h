@@ -71,7 +71,7 @@ struct ConvDesc {
     int nbatch = 1;         // independent problems of this shape in one launch (Winograd positions)
     long in_bs = 0, out_bs = 0;   // 16-byte elements between consecutive problems' input / output buffers
     size_t w_bs = 0;        // floats between consecutive problems' packed weights (the bias is shared)
-    // fused MaxPool2d(2) (fp32 inference, conv_w2d.hip / winograd.hip): the layer also writes max over 2x2 blocks of its activated
+    // fused MaxPool2d(2) (fp32 inference: conv_w2d.hip / winograd.hip; 16-bit storage: conv_qp): the layer also writes max over 2x2 blocks of its activated
     // output into planes [0, cout/4) of `pool` (UtNet.py:99-105: every pooled tensor is a conv output that is also a skip)
     const QpBuf *pool = nullptr;
     // region of interest (rows == 0: the whole layer).  3x3 layers (conv_w2d, three-pass F(6x6)): rectangle [r0, r0 + rows) x
@@ -83,6 +83,7 @@ struct ConvDesc {
 // scratch that lets every layer split its partial round: 512 work items of 64 x 1024 accumulators
 static const size_t kSplitScratchBytes = (size_t)512 * 64 * 1024 * 4;
 int nd_launch_conv(const ConvDesc &d, hipStream_t stream);
+bool nd_conv_pool_fits(const ConvDesc &d);  // a 16-bit 3x3 launch with d.pool set can pool in its epilogue (else: nd_launch_maxpool2 after it)
 bool nd_conv_roi_fits(const ConvDesc &d);   // a launch restricted to d.roi_* finds a workgroup shape that fits the LDS
 static inline int nd_launch_conv_f32(const ConvDesc &d, hipStream_t stream) { return nd_launch_conv(d, stream); }
 int nd_conv_variant_count();
@@ -125,7 +126,7 @@ static inline int nd_num_cus(int dev, int *out) {
 }
 // the arithmetic switches every flags-taking entry point accepts (include/nind_hip.h: nd_flags); unknown bits are an error
 static inline int nd_check_flags(int flags) {
-    if (flags & ~(ND_FLAG_NO_SPLITK | ND_FLAG_DIRECT_CONV | ND_FLAG_W1D_REGS | ND_FLAG_FULL_TILES)) ND_FAIL(ND_EINVAL, "unknown flag bits 0x%x", flags);
+    if (flags & ~(ND_FLAG_NO_SPLITK | ND_FLAG_DIRECT_CONV | ND_FLAG_W1D_REGS | ND_FLAG_FULL_TILES | ND_FLAG_UNFUSED_POOL)) ND_FAIL(ND_EINVAL, "unknown flag bits 0x%x", flags);
     return ND_OK;
 }
 const char *nd_conv_variant_label(int v);

@@ -419,10 +419,13 @@ int run_stack(int f, int act, int dt, const float *blob, const Plan &pl, hipStre
         // the pool kernel re-read the whole skip tensor from HBM (2.4 % of the fp32 conv stack)
         const bool next_is_pool = this_step + 1 < kNumSteps && kSteps[this_step + 1].layer < 0;
         const bool w2d = form == FORM_W1D4 && !pre && !(flags & ND_FLAG_W1D_REGS);
-        if (next_is_pool && !pre && (w2d || form == FORM_WINO3P)) {
+        if (next_is_pool && !pre && !(flags & ND_FLAG_UNFUSED_POOL)) {
             pool_view = pl.buf[kSteps[this_step + 1].dst];
             d.pool = &pool_view;
-            pool_done = true;
+            // fp32: conv_w2d and the three-pass output transform pool; 16-bit storage: conv_qp over 2-row bands of pixels, where a
+            // workgroup shape fits the longer stage image
+            pool_done = w2d || form == FORM_WINO3P || (form == FORM_DIRECT && dt != ND_F32 && nd_conv_pool_fits(d));
+            if (!pool_done) d.pool = nullptr;
         }
         if (form == FORM_W1D4 || form == FORM_W1D2) {
             // narrow layer: 1-D Winograd along x inside the implicit-GEMM kernel; F(4,3), or F(2,3) on rows too wide for it

@@ -116,10 +116,12 @@ class UtNet(nn.Module):
     #   w1d_regs = True  -> A/B switch: the fused 1-D Winograd layers through conv_w1d (transform in registers) instead of conv_w2d
     #   useful_only = False -> the fused denoise loop computes whole tiles in every layer (as forward() always does) instead of
     #                          only what the useful centre of a tile depends on in the last decoder levels (same canvas)
+    #   fused_pool = False -> A/B switch: every MaxPool2d(2) as its own kernel instead of from the producing layer's epilogue (same values)
     split_k = True
     winograd = True
     w1d_regs = False
     useful_only = True
+    fused_pool = True
 
     def __init__(self, funit=64, activation='PReLU'):
         super().__init__()
@@ -172,7 +174,8 @@ class UtNet(nn.Module):
     @property
     def flags(self):
         return ((0 if self.split_k else _lib.FLAG_NO_SPLITK) | (0 if self.winograd else _lib.FLAG_DIRECT_CONV) |
-                (_lib.FLAG_W1D_REGS if self.w1d_regs else 0) | (0 if self.useful_only else _lib.FLAG_FULL_TILES))
+                (_lib.FLAG_W1D_REGS if self.w1d_regs else 0) | (0 if self.useful_only else _lib.FLAG_FULL_TILES) |
+                (0 if self.fused_pool else _lib.FLAG_UNFUSED_POOL))
 
     # ------------------------------------------------------------------ weights
     def _weights_key(self, device):

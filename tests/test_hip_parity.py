@@ -600,6 +600,31 @@ def test_device_side_sample_conversion_is_bit_identical(dev, tmp_path):
             assert f1.read() == f2.read(), ext
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_16bit_pool_fused_into_conv_epilogue(dev, dtype):
+    """16-bit storage: the MaxPool2d(2) that follows convsN.2 is written from that layer's epilogue (conv_qp walks the pixels in
+    2-row bands, so a 2x2 block is a quad of adjacent lanes: maximum by two DPP permutes, then the same rounding and 16-byte store).
+    The pooled values are those of the separate kernel bit for bit (ND_FLAG_UNFUSED_POOL), on narrow and production-width nets,
+    tiles that do and do not divide into whole bands, and the fused path really runs (the pool steps take no time of their own)."""
+    import bench
+    from nind_denoise_amd.networks.UtNet import UtNet
+    for funit, cs, batch, seed in ((16, 104, 3, 7), (16, 136, 5, 8), (64, 264, 4, 9)):
+        net = UtNet(funit=funit)
+        net.load_state_dict(synth.make_utnet_state_dict(funit=funit, seed=seed))
+        net = net.eval().to(dev).set_compute_dtype(dtype)
+        net.split_k = False      # (a pooling layer keeps its tiles whole; the separate-kernel run must not re-associate them either)
+        x = torch.rand(batch, 3, cs, cs, generator=torch.Generator().manual_seed(seed)).to(dev)
+        with torch.no_grad():
+            y_fused = net(x).clone()
+            net.fused_pool = False
+            y_sep = net(x).clone()
+            net.fused_pool = True
+        assert torch.isfinite(y_fused).all() and torch.equal(y_fused, y_sep), (funit, cs)
+    steps = bench.conv_stack_profile(net, 264, 4, dev, reps=1)
+    pools = [s_ for s_ in steps if s_["form"] == "pool"]   # (fused on the two large levels; the small ones keep the separate kernel)
+    assert len(pools) == 4 and all(s_["ms"] < 0.02 for s_ in pools[:2]), [s_["ms"] for s_ in pools]
+
+
 def test_resident_worker_serves_cli_clients(dev, tmp_path):
     """Row f2: `python -m nind_denoise_amd.serve --socket PATH` started once, three images through
     `python -m nind_denoise_amd.denoise_image ... --server PATH` clients (fresh light processes that load neither torch nor the

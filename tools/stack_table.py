@@ -31,6 +31,7 @@ def main():
     net.split_k = not (a.flags & 1)
     net.winograd = not (a.flags & 2)
     net.w1d_regs = bool(a.flags & 4)
+    net.fused_pool = not (a.flags & 16)
     steps = bench.conv_stack_profile(net, a.cs, a.batch, dev, reps=a.reps, crop=a.crop)
     tot = 0.0
     print(f"{'layer':12s} {'form':12s} {'ms':>8s} {'xf_in':>7s} {'TB/s':>5s} {'gemm':>7s} {'xf_out':>7s} {'TB/s':>5s} {'exec TF':>8s} {'alg TF':>8s}")
