@@ -227,9 +227,13 @@ static int pick_variant(const ConvDesc &d, int M) {
             const int cus = g_num_cus.load(std::memory_order_relaxed) > 0 ? g_num_cus.load(std::memory_order_relaxed) : 256;
             double best = 0;
             int best_v = -1;
-            // (16-bit storage: the MFMAs are 16x faster, the LDS-DMA stream per CU is the bound -> the 128 x 512 tile, 35 KB of DMA
-            // per 32k outputs against 42 (64 x 1024) and 52 (64 x 512), where the layer has 128 output channels to fill it)
-            const struct { int v; double unit; } cand[] = {{0, 1.0}, {11, dt == ND_F32 ? 0.955 : 0.85}, {14, dt == ND_F32 ? 2.0 : 0.72}};
+            // (16-bit units re-measured in round 3, after the 16-byte epilogue stores, on every 3x3 layer of UtNet(64) at 160 tiles of 264:
+            //  the 64 x 1024 shape is now 2 - 4 % ahead of 128 x 512 from 128 channels up -- the wider tile's advantage was its
+            //  cheaper store epilogue -- and 5 - 10 % ahead of 64 x 512; the 128 x 512 shape keeps the 13-pixel bottom, where its
+            //  tiles quantise better: tools/sweep_variants.sh)
+            const struct { int v; double unit; } cand[] = {{0, dt == ND_F32 ? 1.0 : 0.92}, {11, dt == ND_F32 ? 0.955 : 0.85}, {14, dt == ND_F32 ? 2.0 : 1.75}};
+            // (the cost below is rounds x chunks x N-tile pixels x unit: a 128 x 512 tile does the work of a 64 x 1024 one, so equal
+            //  cost per tile is unit(14) = 2 x unit(11); 1.75 / 0.85 = 2.06 says "3 % slower per tile")
             for (const auto &c : cand) {
                 const Variant &V = variant_at(g0 + c.v);
                 if (c.v == 14 && (M < 128 || dt == ND_F32)) continue;

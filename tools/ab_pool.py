@@ -14,7 +14,7 @@ for dtype, geom, batch in (("bf16", (6000, 4000, 264, 200, 64), 160), ("f16", (9
             cv.zero_(); pipeline.denoise_frame(net, img, cs, ucs, ol, batch=batch, canvas=cv)
         torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
     run(2)
-    for rep in range(3):
+    for rep in range(2):
         for fused in (True, False):
             net.fused_pool = fused
             run(1)
