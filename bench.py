@@ -419,8 +419,8 @@ def time_frames(net, img, canvas, cs, ucs, ol, batch, steps, warmup):
 
 OTHER_CONFIGS = [
     # key, BASELINE config, (W, H, cs, ucs, ol), dtype, tiles per launch, parity bar (PSNR dB against the fp32 oracle; None: the fp32 bar)
-    ("bf16_g24", "configs[2] per-GPU work: 24 MP frame, bf16 storage", (6000, 4000, 264, 200, 64), "bf16", 160, 65.0),
-    ("f16_g61", "configs[3]: 61 MP frame (9504x6336), cs=520 (nearest valid to 512), fp16 storage", (9504, 6336, 520, 456, 64), "f16", 40, 85.0),
+    ("bf16_g24", "configs[2] per-GPU work: 24 MP frame, bf16 storage", (6000, 4000, 264, 200, 64), "bf16", 320, 65.0),
+    ("f16_g61", "configs[3]: 61 MP frame (9504x6336), cs=520 (nearest valid to 512), fp16 storage", (9504, 6336, 520, 456, 64), "f16", 80, 85.0),
     ("f32_g24d", "configs[1] at the shipped default tiling (CS_UTNET, UCS_UTNET = 504, 480, overlap 6)", (6000, 4000, 504, 480, 6), "f32", 64, None),
 ]
 
