@@ -70,7 +70,7 @@ typedef enum nd_flags {
                                  the network output before the canvas +=) -- same canvas, 19 % less work at cs 264 / ucs 200    */
 } nd_flags;
 
-int nd_version(void);
+int nd_version(void);   /* 103 = this header */
 const char *nd_last_error(void);
 
 /* ---------------------------------------------------------------- tile geometry (host, pure integer)

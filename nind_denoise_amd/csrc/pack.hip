@@ -28,7 +28,7 @@ void nd_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *nd_last_error(void) { return g_err; }
-extern "C" int nd_version(void) { return 100; }
+extern "C" int nd_version(void) { return 103; }   // 103: round-3 ABI (train forward / backward halves, gradient bucket events, ND_FLAG_UNFUSED_POOL, GEMM row order of the 2x2 stride-2 transposes)
 
 static inline uint16_t f32_to_bf16_rne(float f) {
     uint32_t u;
