@@ -662,13 +662,22 @@ def test_resident_worker_serves_cli_clients(dev, tmp_path):
             assert r.returncode == 0, r.stdout + r.stderr
             assert "Elapsed time: " in r.stdout and f"Wrote denoised image to {tmp_path}/out{k}.tiff" in r.stdout
             assert "| torch" not in r.stderr and "numpy" not in r.stderr and "ctypes" not in r.stderr, "client imported heavy modules"
+        # three clients at once: one worker thread per connection, the device sections serialised behind the lock
+        ps = [subprocess.Popen(base[:1] + base[3:] + ["--input", f"in{k}.tif", "--output", f"par{k}.tiff", "--server", sock], env=env, cwd=tmp_path,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for k in range(3)]
+        for k, p_ in enumerate(ps):
+            o, e = p_.communicate(timeout=300)
+            assert p_.returncode == 0 and f"par{k}.tiff" in o, o + e
+        for k in range(3):
+            with open(tmp_path / f"out{k}.tiff", "rb") as f1, open(tmp_path / f"par{k}.tiff", "rb") as f2:
+                assert f1.read() == f2.read()
         # environment variable instead of the flag; an invalid tile size comes back as the CLI's own message and status
         r = subprocess.run(base[:1] + base[3:-8] + ["--cs", "128", "--ucs", "88", "--input", "in0.tif", "--output", "bad.tiff"],
                            env=dict(env, NIND_DENOISE_SERVER=sock), cwd=tmp_path, capture_output=True, text=True, timeout=300)
         assert r.returncode == 1 and "not a valid UtNet tile size" in r.stderr and not os.path.exists(tmp_path / "bad.tiff")
         r = subprocess.run([sys.executable, "-m", "nind_denoise_amd.client", "--server", sock, "--ping"], env=env, cwd=tmp_path,
                            capture_output=True, text=True, timeout=60)
-        assert r.returncode == 0 and "4 request(s) served, 1 model(s) resident" in r.stdout, r.stdout + r.stderr
+        assert r.returncode == 0 and "7 request(s) served, 1 model(s) resident" in r.stdout, r.stdout + r.stderr
         r = subprocess.run([sys.executable, "-m", "nind_denoise_amd.client", "--server", sock, "--shutdown"], env=env, cwd=tmp_path,
                            capture_output=True, text=True, timeout=60)
         assert r.returncode == 0
