@@ -120,6 +120,9 @@ def load():
         raise NindHipMissing(
             f"{LIB_PATH} not found: build it with `make -C nind_denoise_amd/csrc` (or __graft_entry__.build()). "
             "nind_denoise_amd has no CPU fallback for the denoise hot path.")
+    # torch first: it ships its own HIP runtime, and the process must hold ONE copy -- a libamdhip64 pulled in by this library
+    # before torch loads its own sees no device ("no ROCm-capable device is detected" from the first launch)
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)
